@@ -1,0 +1,173 @@
+/*
+ * fuzzyhip.h -- C ABI of libfuzzyhip.so: the MI355X (gfx950) implementation of the reference's
+ * candidate-scoring loop, FuzzySearch.find_best_matches (reference src/fuzzy_search.py:16-38).
+ *
+ * The reference has no FFI of its own for this path: its boundary is the Python class
+ * `FuzzySearch` (src/fuzzy_search.py:8-38).  tts_amd/fuzzy_search.py keeps that class and its two
+ * signatures byte for byte and binds the entry points below with ctypes; INTEGRATION.md shows the
+ * binding.  Each declaration cites the reference lines it stands in for.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns 0 on success or a negative FZ_ERR_*
+ *     code, and fz_last_error() then returns a message for the calling thread.
+ *   - strings are packed UTF-32 code points + offsets (string i = cps[offs[i] .. offs[i+1]));
+ *     they are ALREADY preprocessed by the host language (lower-casing / full_process depend on
+ *     Python's Unicode tables and stay in Python: SURVEY.md 8b).
+ *   - candidate indices are 64-bit GLOBAL indices: base_index + position in this shard.
+ *   - there is no CPU fallback: every scoring entry point needs a gfx950 device.
+ */
+#ifndef FUZZYHIP_H
+#define FUZZYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FZ_VERSION 100 /* 0.1.0 */
+
+enum {
+    FZ_OK = 0,
+    FZ_ERR_INVALID = -1,   /* bad argument */
+    FZ_ERR_HIP = -2,       /* a HIP runtime call failed (message has the HIP error string) */
+    FZ_ERR_ALPHABET = -3,  /* corpus has more distinct code points than the symbol table holds */
+    FZ_ERR_TOO_LONG = -4,  /* query pattern / candidate longer than the kernels support */
+    FZ_ERR_LIMIT = -5,     /* k or another size beyond a documented limit */
+    FZ_ERR_NO_DEVICE = -6  /* no usable GPU */
+};
+
+/* scorers; names follow thefuzz.fuzz (the library the reference calls) */
+typedef enum {
+    FZ_TOKEN_SET = 0,   /* fuzz.token_set_ratio  -- reference src/fuzzy_search.py:26, app.py:1026 */
+    FZ_RATIO = 1,       /* fuzz.ratio            -- reference app.py:1010 */
+    FZ_TOKEN_SORT = 2,  /* fuzz.token_sort_ratio -- BASELINE.json config 5 */
+    FZ_PARTIAL = 3,     /* fuzz.partial_ratio    -- reference app.py:1023 */
+    FZ_LEVENSHTEIN = 4  /* uniform-cost Levenshtein similarity -- reference app.py:296-317,429-432 */
+} fz_scorer;
+
+/* limits */
+#define FZ_MAX_K 1024u            /* top-k size */
+#define FZ_MAX_PATTERN 1024u      /* query pattern length in code points incl. token separators */
+#define FZ_MAX_CAND_LEN 16000u    /* canonical candidate length in code points */
+
+typedef struct fz_corpus fz_corpus;
+
+typedef struct {
+    uint64_t n;              /* candidates in this shard */
+    uint64_t base_index;     /* global index of candidate 0 */
+    uint64_t vocab_size;     /* distinct tokens */
+    uint32_t alphabet_size;  /* distinct code points (+2 reserved symbols) */
+    uint32_t n_tiles;        /* 64-candidate tiles */
+    uint32_t max_len;        /* longest canonical candidate (symbols, incl. trailing separator) */
+    uint32_t max_tokens;     /* most tokens in one candidate */
+    uint64_t device_bytes;   /* HBM held by the corpus (without the query workspace) */
+    uint64_t total_symbols;  /* sum of canonical lengths without the trailing separator */
+    uint64_t total_tokens;   /* sum of token counts */
+    int32_t device;
+} fz_info;
+
+typedef struct {
+    float score_ms;     /* hipEvent time of the scoring kernels of the last query call */
+    float select_ms;    /* hipEvent time of the top-k selection kernels of the last call */
+    float total_ms;     /* hipEvent time from first upload to last download of the last call */
+    uint32_t score_launches;
+    uint32_t select_launches;
+    uint64_t pairs;     /* query x candidate pairs scored by the last call */
+    double host_prep_ms;/* wall time spent building query tables on the host */
+} fz_timing;
+
+/* library version (FZ_VERSION of the build) */
+int fz_version(void);
+
+/* message of the last error raised on the calling thread ("" when none) */
+const char *fz_last_error(void);
+
+/* number of visible HIP devices (0 and FZ_ERR_NO_DEVICE when none) */
+int fz_device_count(int *out_n);
+
+/*
+ * fz_corpus_create -- stands in for FuzzySearch.__init__ (reference src/fuzzy_search.py:10-14),
+ * which only stores the candidate list.  Here the list is tokenised, each candidate is reduced to
+ * its canonical form (sorted unique tokens, what token_set_ratio compares), mapped to 8-bit symbols,
+ * length-sorted into 64-candidate tiles (code-point-major, so loads coalesce) and uploaded to HBM
+ * on `device`.  The candidates are immutable afterwards (reference: the lists are never mutated).
+ *   cps/offs : n preprocessed strings, offs has n+1 entries
+ *   base_index : global index of candidate 0 (contiguous index-range sharding)
+ */
+int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
+                     uint64_t base_index, fz_corpus **out);
+
+/* frees device and host memory of a corpus (reference: garbage collection of the lists) */
+void fz_corpus_destroy(fz_corpus *c);
+
+int fz_corpus_info(const fz_corpus *c, fz_info *out);
+
+/* run later kernels on the caller's hipStream_t (NULL = the corpus' own stream) */
+int fz_set_stream(fz_corpus *c, void *hip_stream);
+
+/* bound on the device workspace the score matrix may take (bytes; default 4 GiB) */
+int fz_set_workspace_limit(fz_corpus *c, uint64_t bytes);
+
+/*
+ * fz_query_topk -- the loop, threshold, stable sort and slice of find_best_matches
+ * (reference src/fuzzy_search.py:22-38) for nq queries at once.
+ *   min_score : smallest integer score that passes `score/100.0 >= threshold` (host computes it
+ *               with Python floats: src/fuzzy_search.py:29-31)
+ *   k         : TOP_N_MATCHES_INT (src/fuzzy_search.py:38), <= FZ_MAX_K
+ *   out_idx   : nq*k global candidate indices, row q sorted by (score desc, index asc) -- the order
+ *               Python's stable sort(reverse=True) yields (src/fuzzy_search.py:35)
+ *   out_score : nq*k integer scores 0..100 (the reference's similarity_score before /100.0)
+ *   out_cnt   : nq result counts (<= k)
+ * Empty query, empty corpus, k == 0: zero results, not an error.
+ */
+int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                  int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx, int32_t *out_score,
+                  uint32_t *out_cnt);
+
+/*
+ * fz_query_topk_keys -- same work, results as packed sort keys for the multi-GPU exchange
+ * (SURVEY.md 8e): key = (score << 40) | ((2^40-1) - global_index); larger key = better match;
+ * rows padded with 0.  `out_keys_device` is a DEVICE pointer to nq*k u64 (the buffer the RCCL
+ * all-gather sends); `out_cnt_device` a DEVICE pointer to nq u32 or NULL.  Asynchronous on the
+ * corpus' stream when `sync` is 0.  No counterpart in the reference (it has no multi-GPU path).
+ */
+int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                       int scorer, int32_t min_score, uint32_t k, uint64_t *out_keys_device,
+                       uint32_t *out_cnt_device, int sync);
+
+/*
+ * fz_merge_topk -- deterministic merge of n_lists per-shard key lists (each nq*k keys as written
+ * by fz_query_topk_keys, gathered in any order) into the global top-k: descending key, i.e.
+ * (score desc, global index asc).  Host code; it is the tail of find_best_matches' sort + slice
+ * (src/fuzzy_search.py:35-38) for a sharded corpus.
+ */
+int fz_merge_topk(const uint64_t *keys, uint32_t n_lists, uint32_t nq, uint32_t k,
+                  uint64_t *out_idx, int32_t *out_score, uint32_t *out_cnt);
+
+/*
+ * fz_score_all -- every integer score of nq queries against every candidate, in ORIGINAL
+ * candidate order (out_scores[q*n + i], host memory).  This is `similarity_score` of
+ * src/fuzzy_search.py:26 for all i; used by the parity tests.
+ */
+int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                 int scorer, uint8_t *out_scores);
+
+/*
+ * fz_distance_batch -- raw distances of n_pairs explicit (a_i, b_i) string pairs, computed by the
+ * same bit-parallel device routines the scorers use.
+ *   kind 0: InDel distance |a|+|b|-2*LCS (what thefuzz's ratios normalise)
+ *   kind 1: uniform-cost Levenshtein (reference app.py:296-317)
+ */
+int fz_distance_batch(int device, int kind, const uint32_t *a_cps, const uint64_t *a_offs,
+                      const uint32_t *b_cps, const uint64_t *b_offs, uint64_t n_pairs,
+                      uint32_t *out_dist);
+
+/* kernel timings of the last query call on this corpus (hipEvents on its stream) */
+int fz_last_timing(const fz_corpus *c, fz_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUZZYHIP_H */

@@ -1,0 +1,8 @@
+"""tts_amd -- MI355X-native implementation of the candidate-scoring loop of the reference's
+``src/fuzzy_search.py``.  ``FuzzySearch`` is the drop-in class; ``Corpus`` the
+handle-level API over ``libfuzzyhip.so``."""
+from .config import FUZZY_SEARCH_THRESHOLD_FLOAT, TOP_N_MATCHES_INT
+from .corpus import Corpus, merge_topk
+from .fuzzy_search import FuzzySearch
+
+__all__ = ["FuzzySearch", "Corpus", "merge_topk", "TOP_N_MATCHES_INT", "FUZZY_SEARCH_THRESHOLD_FLOAT"]

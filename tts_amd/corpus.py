@@ -1,0 +1,151 @@
+"""``Corpus``: a candidate list resident in HBM behind an opaque ``fz_corpus*`` handle.
+
+Thin, typed wrapper over the C ABI (``include/fuzzyhip.h``): all scoring happens in
+``libfuzzyhip.so`` on the GPU.  Used by ``FuzzySearch`` (the reference's class, one corpus per entity
+list) and by ``bench.py`` / the tests directly."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .preprocess import pack_prepared, prepare, prepare_and_pack
+
+
+def _u32(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_u32p)
+
+
+def _u64(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_u64p)
+
+
+class Corpus:
+    """Candidates of one shard, tokenised, canonicalised and uploaded once (``fz_corpus_create``)."""
+
+    def __init__(self, cps: np.ndarray, offs: np.ndarray, device: int = 0, base_index: int = 0):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        cps = np.ascontiguousarray(cps, dtype=np.uint32)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        if offs.ndim != 1 or offs.size < 1:
+            raise ValueError("offs must hold n+1 offsets")
+        self.n = int(offs.size - 1)
+        self.device = int(device)
+        self.base_index = int(base_index)
+        if cps.size == 0:
+            cps = np.zeros(1, dtype=np.uint32)
+        _lib.check(self._lib.fz_corpus_create(_u32(cps), _u64(offs), self.n, self.device,
+                                              self.base_index, ctypes.byref(self._h)))
+
+    # -- construction helpers ------------------------------------------------------------------
+    @classmethod
+    def from_strings(cls, items: Sequence[str], device: int = 0, base_index: int = 0) -> "Corpus":
+        """Raw application strings: applies the reference's lower-casing + thefuzz ``full_process``."""
+        cps, offs = prepare_and_pack(items)
+        return cls(cps, offs, device=device, base_index=base_index)
+
+    @classmethod
+    def from_prepared(cls, items: Sequence[str], device: int = 0, base_index: int = 0) -> "Corpus":
+        cps, offs = pack_prepared(items)
+        return cls(cps, offs, device=device, base_index=base_index)
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.fz_corpus_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _handle(self):
+        if not self._h.value:
+            raise RuntimeError("corpus is closed")
+        return self._h
+
+    # -- queries -------------------------------------------------------------------------------
+    @staticmethod
+    def _pack_queries(queries) -> Tuple[np.ndarray, np.ndarray, int]:
+        if isinstance(queries, tuple) and len(queries) == 2 and isinstance(queries[0], np.ndarray):
+            q_cps = np.ascontiguousarray(queries[0], dtype=np.uint32)
+            q_offs = np.ascontiguousarray(queries[1], dtype=np.uint64)
+            if q_cps.size == 0:
+                q_cps = np.zeros(1, dtype=np.uint32)
+            return q_cps, q_offs, int(q_offs.size - 1)
+        q_cps, q_offs = pack_prepared(list(queries))
+        return q_cps, q_offs, int(q_offs.size - 1)
+
+    def topk(self, queries, min_score: int, k: int, scorer: int = _lib.TOKEN_SET):
+        """Prepared queries (list of str, or (cps, offs)) -> (idx[nq,k] u64, score[nq,k] i32, cnt[nq])."""
+        q_cps, q_offs, nq = self._pack_queries(queries)
+        idx = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        score = np.zeros((nq, max(k, 1)), dtype=np.int32)
+        cnt = np.zeros(max(nq, 1), dtype=np.uint32)
+        _lib.check(self._lib.fz_query_topk(self._handle(), _u32(q_cps), _u64(q_offs), nq, int(scorer),
+                                           int(min_score), int(k), _u64(idx),
+                                           score.ctypes.data_as(_lib.c_i32p), _u32(cnt)))
+        return idx[:, :k], score[:, :k], cnt[:nq]
+
+    def topk_keys_device(self, queries, min_score: int, k: int, keys_ptr: int, cnt_ptr: int = 0,
+                         scorer: int = _lib.TOKEN_SET, sync: bool = True) -> int:
+        """Per-shard top-k as packed keys written to DEVICE memory (for the RCCL all-gather)."""
+        q_cps, q_offs, nq = self._pack_queries(queries)
+        _lib.check(self._lib.fz_query_topk_keys(self._handle(), _u32(q_cps), _u64(q_offs), nq,
+                                                int(scorer), int(min_score), int(k),
+                                                ctypes.c_void_p(keys_ptr),
+                                                ctypes.c_void_p(cnt_ptr) if cnt_ptr else None,
+                                                1 if sync else 0))
+        return nq
+
+    def score_all(self, queries, scorer: int = _lib.TOKEN_SET) -> np.ndarray:
+        """Every integer score, original candidate order: uint8 [nq, n]."""
+        q_cps, q_offs, nq = self._pack_queries(queries)
+        out = np.zeros((max(nq, 1), max(self.n, 1)), dtype=np.uint8)
+        _lib.check(self._lib.fz_score_all(self._handle(), _u32(q_cps), _u64(q_offs), nq, int(scorer),
+                                          out.ctypes.data_as(_lib.c_u8p)))
+        return out[:nq, :self.n]
+
+    # -- introspection -------------------------------------------------------------------------
+    def info(self) -> dict:
+        inf = _lib.FzInfo()
+        _lib.check(self._lib.fz_corpus_info(self._handle(), ctypes.byref(inf)))
+        return {name: getattr(inf, name) for name, _ in inf._fields_}
+
+    def timing(self) -> dict:
+        t = _lib.FzTiming()
+        _lib.check(self._lib.fz_last_timing(self._handle(), ctypes.byref(t)))
+        return {name: getattr(t, name) for name, _ in t._fields_}
+
+    def set_stream(self, stream_ptr: Optional[int]) -> None:
+        _lib.check(self._lib.fz_set_stream(self._handle(), ctypes.c_void_p(stream_ptr or 0)))
+
+    def set_workspace_limit(self, nbytes: int) -> None:
+        _lib.check(self._lib.fz_set_workspace_limit(self._handle(), int(nbytes)))
+
+
+def merge_topk(keys: np.ndarray, n_lists: int, nq: int, k: int):
+    """Deterministic merge of gathered per-shard key lists [n_lists, nq, k] (``fz_merge_topk``)."""
+    lib = _lib.load()
+    keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1)
+    if keys.size != n_lists * nq * k:
+        raise ValueError("keys must hold n_lists*nq*k entries")
+    if keys.size == 0:
+        keys = np.zeros(1, dtype=np.uint64)
+    idx = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+    score = np.zeros((nq, max(k, 1)), dtype=np.int32)
+    cnt = np.zeros(max(nq, 1), dtype=np.uint32)
+    _lib.check(lib.fz_merge_topk(_u64(keys), n_lists, nq, k, _u64(idx),
+                                 score.ctypes.data_as(_lib.c_i32p), _u32(cnt)))
+    return idx[:, :k], score[:, :k], cnt[:nq]

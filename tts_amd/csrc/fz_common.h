@@ -1,0 +1,71 @@
+// fz_common.h -- structures shared by the host side (fz_host.cpp) and the gfx950 kernels
+// (fz_kernels.hip) of libfuzzyhip.so.  See DESIGN.md for the HBM layout these describe.
+#pragma once
+#include <stdint.h>
+
+#define FZ_TILE 64u          // candidates per tile = lanes per wavefront
+#define FZ_SYM_NULL 0u       // padding symbol: its Peq row is all zero, so it never changes the state
+#define FZ_SYM_SPACE 1u      // token separator
+#define FZ_TOK_NONE 0xFFFFFFFFu
+#define FZ_IDX_BITS 40
+#define FZ_IDX_MASK ((1ull << FZ_IDX_BITS) - 1ull)
+
+// One 64-candidate tile.  Symbols: dword d of lane l at sym[coff + d*64 + l] (4 symbols per dword,
+// little endian).  Tokens: slot i of lane l at tokid[toff + i*64 + l] / tokend[toff + i*64 + l].
+struct FzTile {
+    uint32_t coff;   // dword offset into the symbol array
+    uint32_t toff;   // element offset into the token arrays
+    uint16_t ndw;    // symbol dwords per lane in this tile (max over its candidates)
+    uint16_t ntok;   // token slots per lane in this tile (max over its candidates)
+};
+
+// One prepared query (token_set / token_sort / ratio all use it; see fz_host.cpp prepare_query).
+struct FzQuery {
+    uint32_t peq_off;    // dword offset of this query's Peq table [alphabet][W] in the query blob
+    uint32_t tok_off;    // element offset of its (id, pos, len1) token triples, sorted by id
+    uint32_t n_ids;      // tokens that exist in the corpus vocabulary (only those can intersect)
+    uint32_t n_tok;      // all tokens of the query (0 => every score is 0)
+    uint32_t m;          // pattern length: sum(len+1) over tokens (each token + one separator)
+    uint32_t out_row;    // row of the score matrix this query writes
+    uint32_t pad0, pad1;
+};
+
+// Round-to-nearest tie tables (see fz_host.cpp make_tie_table): bit q says whether the exact value
+// q + 0.5 rounds up under the scorer's own fp64 formula.
+struct FzTies {
+    uint64_t lo, hi;
+};
+
+struct FzScoreParams {
+    const uint32_t *sym;
+    const uint32_t *tokid;
+    const uint16_t *tokend;
+    const FzTile *tiles;
+    uint32_t ntiles;
+    uint32_t tiles_per_block;
+    uint32_t alphabet;        // rows of a Peq table
+    uint32_t pmax;            // capacity of the per-query token arrays in LDS
+    uint32_t ntkw;            // text keep-mask words per lane (ceil(max ndw / 8))
+    uint32_t nwaves;          // waves per block
+    const FzQuery *queries;   // queries of this launch (blockIdx.y indexes it)
+    const uint32_t *qblob;    // Peq tables
+    const uint32_t *qtok_id;
+    const uint32_t *qtok_pos;
+    const uint32_t *qtok_len1;
+    uint8_t *scores;          // [rows][row_stride]
+    uint64_t row_stride;
+    FzTies ties;
+};
+
+struct FzSelectParams {
+    const uint8_t *scores;
+    uint64_t row_stride;
+    uint32_t n;               // valid candidates (physical positions >= n are padding)
+    const uint32_t *orig_of_phys;
+    const uint32_t *phys_of_orig;
+    int32_t min_score;
+    uint32_t k;
+    uint64_t base_index;
+    uint64_t *out_keys;       // [rows][k]
+    uint32_t *out_cnt;        // [rows] or null
+};

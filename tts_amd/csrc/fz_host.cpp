@@ -1,0 +1,695 @@
+// fz_host.cpp -- host side of libfuzzyhip.so: corpus ingest, query preparation, launches, C ABI.
+//
+// Reference path: FuzzySearch.__init__ / find_best_matches (reference src/fuzzy_search.py:10-38).
+// Nothing here scores on the CPU: without a gfx950 device every scoring entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "fuzzyhip.h"
+#include "fz_common.h"
+
+// from fz_kernels.hip
+int fz_pick_width(uint32_t m);
+size_t fz_score_lds_bytes(int W, const FzScoreParams &p);
+hipError_t fz_launch_score(int W, const FzScoreParams &p, uint32_t nq, hipStream_t st);
+hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(FZ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// tokens
+// ---------------------------------------------------------------------------------------------
+// the characters Python's str.split() (and rapidfuzz's tokeniser) split on
+static inline bool is_space(uint32_t c)
+{
+    if (c == 0x20u) return true;
+    if (c < 0x85u) return (c >= 0x09u && c <= 0x0Du) || (c >= 0x1Cu && c <= 0x1Fu);
+    return c == 0x85u || c == 0xA0u || c == 0x1680u || (c >= 0x2000u && c <= 0x200Au) ||
+           c == 0x2028u || c == 0x2029u || c == 0x202Fu || c == 0x205Fu || c == 0x3000u;
+}
+
+using Tok = std::u32string_view;
+
+// whitespace split, sort by code point, optionally drop repeats: sorted(set(s.split()))
+static void split_sorted(const uint32_t *s, uint64_t n, bool dedupe, std::vector<Tok> &out)
+{
+    out.clear();
+    const char32_t *p = reinterpret_cast<const char32_t *>(s);
+    uint64_t i = 0;
+    while (i < n) {
+        while (i < n && is_space(s[i])) ++i;
+        if (i >= n) break;
+        uint64_t st = i;
+        while (i < n && !is_space(s[i])) ++i;
+        out.emplace_back(p + st, (size_t)(i - st));
+    }
+    std::sort(out.begin(), out.end());          // u32string_view compares by code point
+    if (dedupe) out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+struct TokHash {
+    size_t operator()(Tok t) const noexcept
+    {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)t.size();
+        for (char32_t ch : t) {
+            h ^= (uint64_t)ch;
+            h *= 0x100000001B3ull;
+            h ^= h >> 29;
+        }
+        return (size_t)h;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// corpus
+// ---------------------------------------------------------------------------------------------
+struct fz_corpus {
+    int device = 0;
+    uint64_t base = 0, n = 0;
+    uint32_t npad = 0, ntiles = 0, max_ndw = 0, max_len = 0, max_tok = 0, alphabet = 2;
+    uint64_t total_symbols = 0, total_tokens = 0, device_bytes = 0;
+
+    // host-side dictionaries the query preparation needs
+    std::vector<uint8_t> sym_of_cp;                       // code point -> symbol (0 = not in corpus)
+    std::deque<std::u32string> vocab_store;               // stable storage of the token strings
+    std::unordered_map<Tok, uint32_t, TokHash> vocab;     // token -> id
+
+    // device corpus
+    uint32_t *d_sym = nullptr, *d_tokid = nullptr, *d_orig_of_phys = nullptr, *d_phys_of_orig = nullptr;
+    uint16_t *d_tokend = nullptr;
+    FzTile *d_tiles = nullptr;
+    std::vector<uint32_t> h_orig_of_phys;
+
+    // query-time state
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    uint64_t ws_limit = 4ull << 30;
+    uint8_t *d_scores = nullptr; size_t scores_cap = 0;
+    uint8_t *d_qbuf = nullptr; size_t qbuf_cap = 0;
+    uint64_t *d_keys = nullptr; size_t keys_cap = 0;
+    uint32_t *d_cnt = nullptr; size_t cnt_cap = 0;
+    std::vector<hipEvent_t> events;
+    fz_timing timing{};
+    std::mutex mu;
+};
+
+static FzTies g_ties_norm_distance, g_ties_norm_sim;
+static std::once_flag g_ties_once;
+
+// The fp64 value of thefuzz's score is only ever ambiguous at exact ties q + 0.5 (fz_kernels.hip
+// fz_round_ratio).  A tie means 200*d/L == 199 - 2q, so evaluate each formula at d = 199 - 2q,
+// L = 200 (same quotient, and the fp64 result depends on the quotient only) and record whether
+// int(round()) -- round-half-even on the computed double -- lands on q + 1.
+static void make_tie_tables()
+{
+    for (int form = 0; form < 2; ++form) {
+        FzTies t{0, 0};
+        for (int q = 0; q < 100; ++q) {
+            volatile double d = 199.0 - 2.0 * q, L = 200.0, x;
+            if (form == 0) {          // rapidfuzz norm_distance<100>: 100 - 100*d/L   (row a6)
+                volatile double num = 100.0 * d;
+                volatile double quo = num / L;
+                x = 100.0 - quo;
+            } else {                  // rapidfuzz ratio: (1 - d/L) * 100              (row a8)
+                volatile double nd = d / L;
+                volatile double ns = 1.0 - nd;
+                x = ns * 100.0;
+            }
+            long r = std::lrint((double)x);   // FE_TONEAREST: ties to even, as Python round()
+            if (r == q + 1) (q < 64 ? t.lo : t.hi) |= 1ull << (q & 63);
+        }
+        (form == 0 ? g_ties_norm_distance : g_ties_norm_sim) = t;
+    }
+}
+
+template <typename T>
+static int upload(T **dptr, const std::vector<T> &h, uint64_t *bytes)
+{
+    size_t sz = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), sz));
+    if (!h.empty()) HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *bytes += sz;
+    return FZ_OK;
+}
+
+extern "C" int fz_version(void) { return FZ_VERSION; }
+
+extern "C" const char *fz_last_error(void) { return g_err.c_str(); }
+
+extern "C" int fz_device_count(int *out_n)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (out_n) *out_n = (e == hipSuccess) ? n : 0;
+    if (e != hipSuccess || n == 0) return fail(FZ_ERR_NO_DEVICE, "no HIP device visible");
+    return FZ_OK;
+}
+
+extern "C" void fz_corpus_destroy(fz_corpus *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    for (void *p : {(void *)c->d_sym, (void *)c->d_tokid, (void *)c->d_tokend, (void *)c->d_tiles,
+                    (void *)c->d_orig_of_phys, (void *)c->d_phys_of_orig, (void *)c->d_scores,
+                    (void *)c->d_qbuf, (void *)c->d_keys, (void *)c->d_cnt})
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
+                                uint64_t base_index, fz_corpus **out)
+{
+    if (!out) return fail(FZ_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (n && (!cps || !offs)) return fail(FZ_ERR_INVALID, "cps/offs null with n > 0");
+    if (n >= 0xFFFFFFFFull - 64) return fail(FZ_ERR_LIMIT, "shard holds %llu candidates; limit is 2^32-65 per shard", (unsigned long long)n);
+    if (base_index + n > FZ_IDX_MASK) return fail(FZ_ERR_LIMIT, "global index beyond 2^40");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FZ_ERR_NO_DEVICE, "no HIP device visible: libfuzzyhip has no CPU path");
+    if (device < 0 || device >= ndev) return fail(FZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+    std::call_once(g_ties_once, make_tie_tables);
+
+    fz_corpus *c = new fz_corpus();
+    c->device = device; c->base = base_index; c->n = n;
+    auto bail = [&](int code) { fz_corpus_destroy(c); return code; };
+
+    // ---- alphabet: every non-separator code point in the input gets an 8-bit symbol ------------
+    {
+        std::vector<uint8_t> seen(0x110000, 0);
+        const uint64_t total = n ? offs[n] : 0;
+        for (uint64_t i = n ? offs[0] : 0; i < total; ++i) {
+            uint32_t cp = cps[i];
+            if (cp >= 0x110000u) return bail(fail(FZ_ERR_INVALID, "code point 0x%x out of range at %llu", cp, (unsigned long long)i));
+            seen[cp] = 1;
+        }
+        c->sym_of_cp.assign(0x110000, 0);
+        uint32_t next = 2;
+        for (uint32_t cp = 0; cp < 0x110000u; ++cp) {
+            if (!seen[cp] || is_space(cp)) continue;
+            if (next > 255u) return bail(fail(FZ_ERR_ALPHABET, "corpus has more than 254 distinct code points; the 8-bit symbol table is full"));
+            c->sym_of_cp[cp] = (uint8_t)next++;
+        }
+        c->alphabet = next;
+    }
+
+    // ---- canonical form of every candidate: sorted unique tokens, each followed by a separator --
+    std::vector<uint8_t> canon;          // symbols, all candidates back to back
+    std::vector<uint64_t> canon_off(n + 1, 0);
+    std::vector<uint32_t> tok_id;        // token ids, all candidates back to back
+    std::vector<uint16_t> tok_end;       // exclusive end (incl. separator) of each token
+    std::vector<uint64_t> tok_off(n + 1, 0);
+    {
+        std::vector<Tok> toks;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (offs[i + 1] < offs[i]) return bail(fail(FZ_ERR_INVALID, "offsets not monotone at %llu", (unsigned long long)i));
+            split_sorted(cps + offs[i], offs[i + 1] - offs[i], true, toks);
+            uint64_t len = 0;
+            for (Tok t : toks) {
+                auto it = c->vocab.find(t);
+                uint32_t id;
+                if (it == c->vocab.end()) {
+                    if (c->vocab.size() >= 0xFFFFFFF0ull) return bail(fail(FZ_ERR_LIMIT, "vocabulary exceeds 2^32 tokens"));
+                    c->vocab_store.emplace_back(t);
+                    id = (uint32_t)c->vocab.size();
+                    c->vocab.emplace(Tok(c->vocab_store.back()), id);
+                } else {
+                    id = it->second;
+                }
+                for (char32_t ch : t) canon.push_back(c->sym_of_cp[(uint32_t)ch]);
+                canon.push_back((uint8_t)FZ_SYM_SPACE);
+                len += t.size() + 1;
+                if (len > FZ_MAX_CAND_LEN) return bail(fail(FZ_ERR_TOO_LONG, "candidate %llu is longer than %u code points", (unsigned long long)i, FZ_MAX_CAND_LEN));
+                tok_id.push_back(id);
+                tok_end.push_back((uint16_t)len);
+            }
+            canon_off[i + 1] = canon.size();
+            tok_off[i + 1] = tok_id.size();
+            c->total_symbols += len ? len - 1 : 0;
+            c->total_tokens += toks.size();
+            c->max_len = std::max<uint32_t>(c->max_len, (uint32_t)len);
+            c->max_tok = std::max<uint32_t>(c->max_tok, (uint32_t)toks.size());
+        }
+    }
+
+    // ---- physical order: sort by (symbol dwords, tokens, original index); tiles of 64 ----------
+    c->ntiles = (uint32_t)((n + FZ_TILE - 1) / FZ_TILE);
+    c->npad = c->ntiles * FZ_TILE;
+    std::vector<uint64_t> keys(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t ndw = (canon_off[i + 1] - canon_off[i] + 3) / 4, nt = tok_off[i + 1] - tok_off[i];
+        keys[i] = (ndw << 48) | (nt << 32) | i;
+    }
+    std::sort(keys.begin(), keys.end());
+    c->h_orig_of_phys.assign(c->npad, 0xFFFFFFFFu);
+    std::vector<uint32_t> phys_of_orig(n);
+    for (uint64_t ph = 0; ph < n; ++ph) {
+        uint32_t o = (uint32_t)(keys[ph] & 0xFFFFFFFFull);
+        c->h_orig_of_phys[ph] = o;
+        phys_of_orig[o] = (uint32_t)ph;
+    }
+    std::vector<FzTile> tiles(c->ntiles);
+    uint64_t sym_words = 0, tok_slots = 0;
+    for (uint32_t t = 0; t < c->ntiles; ++t) {
+        uint32_t ndw = 0, ntok = 0;
+        for (uint32_t l = 0; l < FZ_TILE; ++l) {
+            uint64_t ph = (uint64_t)t * FZ_TILE + l;
+            if (ph >= n) break;
+            uint32_t o = c->h_orig_of_phys[ph];
+            ndw = std::max<uint32_t>(ndw, (uint32_t)((canon_off[o + 1] - canon_off[o] + 3) / 4));
+            ntok = std::max<uint32_t>(ntok, (uint32_t)(tok_off[o + 1] - tok_off[o]));
+        }
+        if (sym_words + (uint64_t)ndw * 64 > 0xFFFFFFFFull || tok_slots + (uint64_t)ntok * 64 > 0xFFFFFFFFull)
+            return bail(fail(FZ_ERR_LIMIT, "shard too large for 32-bit tile offsets; use more shards"));
+        tiles[t].coff = (uint32_t)sym_words; tiles[t].toff = (uint32_t)tok_slots;
+        tiles[t].ndw = (uint16_t)ndw; tiles[t].ntok = (uint16_t)ntok;
+        sym_words += (uint64_t)ndw * 64; tok_slots += (uint64_t)ntok * 64;
+        c->max_ndw = std::max(c->max_ndw, ndw);
+    }
+    std::vector<uint32_t> h_sym(sym_words, 0u);
+    std::vector<uint32_t> h_tokid(tok_slots, FZ_TOK_NONE);
+    std::vector<uint16_t> h_tokend(tok_slots, 0);
+    for (uint32_t t = 0; t < c->ntiles; ++t) {
+        const FzTile &td = tiles[t];
+        for (uint32_t l = 0; l < FZ_TILE; ++l) {
+            uint64_t ph = (uint64_t)t * FZ_TILE + l;
+            uint32_t len = 0, nt = 0;
+            if (ph < n) {
+                uint32_t o = c->h_orig_of_phys[ph];
+                len = (uint32_t)(canon_off[o + 1] - canon_off[o]);
+                nt = (uint32_t)(tok_off[o + 1] - tok_off[o]);
+                const uint8_t *src = canon.data() + canon_off[o];
+                for (uint32_t j = 0; j < len; ++j)
+                    h_sym[td.coff + (uint64_t)(j >> 2) * 64 + l] |= (uint32_t)src[j] << (8 * (j & 3));
+                for (uint32_t i = 0; i < nt; ++i) {
+                    h_tokid[td.toff + (uint64_t)i * 64 + l] = tok_id[tok_off[o] + i];
+                    h_tokend[td.toff + (uint64_t)i * 64 + l] = tok_end[tok_off[o] + i];
+                }
+            }
+            for (uint32_t i = nt; i < td.ntok; ++i) h_tokend[td.toff + (uint64_t)i * 64 + l] = (uint16_t)len;
+        }
+    }
+
+    int rc;
+    if ((rc = upload(&c->d_sym, h_sym, &c->device_bytes)) != FZ_OK) return bail(rc);
+    if ((rc = upload(&c->d_tokid, h_tokid, &c->device_bytes)) != FZ_OK) return bail(rc);
+    if ((rc = upload(&c->d_tokend, h_tokend, &c->device_bytes)) != FZ_OK) return bail(rc);
+    if ((rc = upload(&c->d_tiles, tiles, &c->device_bytes)) != FZ_OK) return bail(rc);
+    if ((rc = upload(&c->d_orig_of_phys, c->h_orig_of_phys, &c->device_bytes)) != FZ_OK) return bail(rc);
+    if ((rc = upload(&c->d_phys_of_orig, phys_of_orig, &c->device_bytes)) != FZ_OK) return bail(rc);
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return bail(fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)));
+    c->stream = c->own_stream;
+    *out = c;
+    return FZ_OK;
+}
+
+extern "C" int fz_corpus_info(const fz_corpus *c, fz_info *o)
+{
+    if (!c || !o) return fail(FZ_ERR_INVALID, "null argument");
+    o->n = c->n; o->base_index = c->base; o->vocab_size = c->vocab.size();
+    o->alphabet_size = c->alphabet; o->n_tiles = c->ntiles; o->max_len = c->max_len;
+    o->max_tokens = c->max_tok; o->device_bytes = c->device_bytes;
+    o->total_symbols = c->total_symbols; o->total_tokens = c->total_tokens; o->device = c->device;
+    return FZ_OK;
+}
+
+extern "C" int fz_set_stream(fz_corpus *c, void *hip_stream)
+{
+    if (!c) return fail(FZ_ERR_INVALID, "null corpus");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return FZ_OK;
+}
+
+extern "C" int fz_set_workspace_limit(fz_corpus *c, uint64_t bytes)
+{
+    if (!c) return fail(FZ_ERR_INVALID, "null corpus");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->ws_limit = std::max<uint64_t>(bytes, 1);
+    return FZ_OK;
+}
+
+extern "C" int fz_last_timing(const fz_corpus *c, fz_timing *out)
+{
+    if (!c || !out) return fail(FZ_ERR_INVALID, "null argument");
+    *out = c->timing;
+    return FZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// query preparation
+// ---------------------------------------------------------------------------------------------
+struct QueryBatch {
+    // per width class W: the prepared queries that use fz_score_general<W>
+    std::map<int, std::vector<FzQuery>> classes;
+    std::vector<uint32_t> peq, tok_id, tok_pos, tok_len1;
+};
+
+// Pattern of a query = its sorted unique tokens, each followed by one separator (m code points).
+// Peq[s][w] has bit (i % 32) of word i / 32 set when pattern position i holds symbol s; code points
+// the corpus never uses get no bit anywhere (they can match nothing).  Tokens known to the corpus
+// vocabulary are listed as (id, first bit, len+1), ascending id, for the kernel's binary search.
+static int prepare_query(const fz_corpus *c, const uint32_t *s, uint64_t n, uint32_t out_row,
+                         QueryBatch &b, std::vector<Tok> &toks)
+{
+    split_sorted(s, n, true, toks);
+    uint64_t m = 0;
+    for (Tok t : toks) m += t.size() + 1;
+    if (m > FZ_MAX_PATTERN) return fail(FZ_ERR_TOO_LONG, "query pattern of %llu code points exceeds FZ_MAX_PATTERN (%u)", (unsigned long long)m, FZ_MAX_PATTERN);
+    const int W = fz_pick_width((uint32_t)m);
+    FzQuery q{};
+    q.peq_off = (uint32_t)b.peq.size();
+    q.tok_off = (uint32_t)b.tok_id.size();
+    q.n_tok = (uint32_t)toks.size();
+    q.m = (uint32_t)m;
+    q.out_row = out_row;
+    b.peq.resize(b.peq.size() + (size_t)c->alphabet * W, 0u);
+    uint32_t *peq = b.peq.data() + q.peq_off;
+    struct Trip { uint32_t id, pos, len1; };
+    std::vector<Trip> trips;
+    uint32_t pos = 0;
+    for (Tok t : toks) {
+        for (size_t j = 0; j < t.size(); ++j) {
+            uint32_t cp = (uint32_t)t[j];
+            uint32_t sym = cp < 0x110000u ? c->sym_of_cp[cp] : 0u;
+            uint32_t bit = pos + (uint32_t)j;
+            if (sym) peq[sym * W + (bit >> 5)] |= 1u << (bit & 31u);
+        }
+        uint32_t sep = pos + (uint32_t)t.size();
+        peq[FZ_SYM_SPACE * W + (sep >> 5)] |= 1u << (sep & 31u);
+        auto it = c->vocab.find(t);
+        if (it != c->vocab.end()) trips.push_back({it->second, pos, (uint32_t)t.size() + 1u});
+        pos = sep + 1u;
+    }
+    std::sort(trips.begin(), trips.end(), [](const Trip &a, const Trip &b2) { return a.id < b2.id; });
+    q.n_ids = (uint32_t)trips.size();
+    for (const Trip &t : trips) { b.tok_id.push_back(t.id); b.tok_pos.push_back(t.pos); b.tok_len1.push_back(t.len1); }
+    b.classes[W].push_back(q);
+    return FZ_OK;
+}
+
+template <typename T>
+static int ensure(T **p, size_t *cap, size_t need_bytes)
+{
+    if (need_bytes <= *cap) return FZ_OK;
+    if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+    size_t sz = need_bytes + need_bytes / 4 + 256;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), sz));
+    *cap = sz;
+    return FZ_OK;
+}
+
+static hipEvent_t get_event(fz_corpus *c, size_t i)
+{
+    while (c->events.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->events.push_back(e);
+    }
+    return c->events[i];
+}
+
+enum RunMode { RUN_TOPK_HOST, RUN_TOPK_DEVICE, RUN_SCORE_ALL };
+
+struct RunOut {
+    uint64_t *idx = nullptr; int32_t *score = nullptr; uint32_t *cnt = nullptr;     // TOPK_HOST
+    uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr; int sync = 1;           // TOPK_DEVICE
+    uint8_t *scores = nullptr;                                                      // SCORE_ALL
+};
+
+static void decode_keys(const uint64_t *keys, uint32_t nq, uint32_t k, uint64_t *idx, int32_t *score, uint32_t *cnt)
+{
+    for (uint32_t q = 0; q < nq; ++q) {
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < k; ++i) {
+            uint64_t key = keys[(uint64_t)q * k + i];
+            if (key == 0ull) {   // padding: a real key is never 0 (global indices stay below 2^40-1)
+                idx[(uint64_t)q * k + i] = 0; score[(uint64_t)q * k + i] = 0;
+                continue;
+            }
+            idx[(uint64_t)q * k + i] = FZ_IDX_MASK - (key & FZ_IDX_MASK);
+            score[(uint64_t)q * k + i] = (int32_t)(key >> FZ_IDX_BITS);
+            ++c;
+        }
+        if (cnt) cnt[q] = c;
+    }
+}
+
+static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                       int scorer, int32_t min_score, uint32_t k, RunMode mode, RunOut &o)
+{
+    if (!c) return fail(FZ_ERR_INVALID, "null corpus");
+    if (nq && (!q_offs || (!q_cps && q_offs[nq] != q_offs[0]))) return fail(FZ_ERR_INVALID, "null query buffers");
+    if (scorer != FZ_TOKEN_SET) return fail(FZ_ERR_INVALID, "scorer %d is not implemented by this build", scorer);
+    if (mode != RUN_SCORE_ALL && k > FZ_MAX_K) return fail(FZ_ERR_LIMIT, "k=%u exceeds FZ_MAX_K=%u", k, FZ_MAX_K);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->timing = fz_timing{};
+
+    const bool topk = mode != RUN_SCORE_ALL;
+    const bool nothing = topk && (k == 0 || c->n == 0 || min_score > 100);
+    uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr;
+    if (topk && nq && k) {
+        if (mode == RUN_TOPK_DEVICE) { d_keys = o.d_keys; d_cnt = o.d_cnt; }
+        else {
+            int rc;
+            if ((rc = ensure(&c->d_keys, &c->keys_cap, (size_t)nq * k * 8)) != FZ_OK) return rc;
+            if ((rc = ensure(&c->d_cnt, &c->cnt_cap, (size_t)nq * 4)) != FZ_OK) return rc;
+            d_keys = c->d_keys; d_cnt = c->d_cnt;
+        }
+    }
+    if (nq == 0) return FZ_OK;
+    if (nothing) {
+        if (mode == RUN_TOPK_HOST) {
+            if (o.cnt) memset(o.cnt, 0, (size_t)nq * 4);
+            if (k) { memset(o.idx, 0, (size_t)nq * k * 8); memset(o.score, 0, (size_t)nq * k * 4); }
+        } else if (k) {
+            HIP_TRY(hipMemsetAsync(d_keys, 0, (size_t)nq * k * 8, st));
+            if (d_cnt) HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)nq * 4, st));
+            if (o.sync) HIP_TRY(hipStreamSynchronize(st));
+        }
+        return FZ_OK;
+    }
+    if (c->n == 0) return FZ_OK;                                  // SCORE_ALL of an empty corpus
+
+    const uint64_t row_stride = c->npad;
+    uint64_t rows_per_chunk = std::max<uint64_t>(1, c->ws_limit / row_stride);
+    rows_per_chunk = std::min<uint64_t>(rows_per_chunk, nq);
+    int rc;
+    if ((rc = ensure(&c->d_scores, &c->scores_cap, (size_t)(rows_per_chunk * row_stride))) != FZ_OK) return rc;
+
+    std::vector<Tok> toks;
+    std::vector<uint8_t> h_rows;
+    size_t ev = 0;
+    std::vector<std::pair<size_t, size_t>> score_spans, select_spans;
+    hipEvent_t ev_first = get_event(c, ev++), ev_last = nullptr;
+    HIP_TRY(hipEventRecord(ev_first, st));
+
+    for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk) {
+        const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, nq - q0);
+        auto t0 = std::chrono::steady_clock::now();
+        QueryBatch b;
+        for (uint32_t r = 0; r < rows; ++r) {
+            const uint64_t qi = q0 + r;
+            if (q_offs[qi + 1] < q_offs[qi]) return fail(FZ_ERR_INVALID, "query offsets not monotone at %llu", (unsigned long long)qi);
+            rc = prepare_query(c, q_cps + q_offs[qi], q_offs[qi + 1] - q_offs[qi], r, b, toks);
+            if (rc != FZ_OK) return rc;
+        }
+        // one device blob: [FzQuery list by class][peq][tok_id][tok_pos][tok_len1]
+        std::vector<FzQuery> qlist;
+        std::vector<std::pair<int, std::pair<uint32_t, uint32_t>>> launches;   // W -> (first, count)
+        for (auto &kv : b.classes) {
+            launches.push_back({kv.first, {(uint32_t)qlist.size(), (uint32_t)kv.second.size()}});
+            qlist.insert(qlist.end(), kv.second.begin(), kv.second.end());
+        }
+        const size_t o_q = 0, o_peq = o_q + qlist.size() * sizeof(FzQuery);
+        const size_t o_id = o_peq + b.peq.size() * 4, o_pos = o_id + b.tok_id.size() * 4;
+        const size_t o_len = o_pos + b.tok_pos.size() * 4, total = o_len + b.tok_len1.size() * 4;
+        std::vector<uint8_t> blob(std::max<size_t>(total, 16));
+        memcpy(blob.data() + o_q, qlist.data(), qlist.size() * sizeof(FzQuery));
+        if (!b.peq.empty()) memcpy(blob.data() + o_peq, b.peq.data(), b.peq.size() * 4);
+        if (!b.tok_id.empty()) {
+            memcpy(blob.data() + o_id, b.tok_id.data(), b.tok_id.size() * 4);
+            memcpy(blob.data() + o_pos, b.tok_pos.data(), b.tok_pos.size() * 4);
+            memcpy(blob.data() + o_len, b.tok_len1.data(), b.tok_len1.size() * 4);
+        }
+        c->timing.host_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if ((rc = ensure(&c->d_qbuf, &c->qbuf_cap, blob.size())) != FZ_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_qbuf, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));          // blob is pageable host memory owned by this scope
+
+        hipEvent_t e0 = get_event(c, ev++), e1 = get_event(c, ev++);
+        if (!e0 || !e1) return fail(FZ_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(e0, st));
+        for (auto &l : launches) {
+            const int W = l.first;
+            const uint32_t first = l.second.first, count = l.second.second;
+            FzScoreParams p{};
+            p.sym = c->d_sym; p.tokid = c->d_tokid; p.tokend = c->d_tokend; p.tiles = c->d_tiles;
+            p.ntiles = c->ntiles; p.alphabet = c->alphabet;
+            uint32_t pmax = 1;
+            for (uint32_t i = 0; i < count; ++i) pmax = std::max(pmax, qlist[first + i].n_ids);
+            p.pmax = pmax;
+            p.ntkw = std::max<uint32_t>(1, (c->max_ndw + 7) / 8);
+            p.nwaves = 4;
+            while (p.nwaves > 1 && fz_score_lds_bytes(W, p) > 64 * 1024) p.nwaves >>= 1;
+            if (fz_score_lds_bytes(W, p) > 160 * 1024)
+                return fail(FZ_ERR_TOO_LONG, "pattern width %d words x candidate length %u does not fit in LDS", W, c->max_len);
+            uint64_t work = (uint64_t)c->ntiles * count;
+            uint32_t tpb = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(p.nwaves, work / 8192));
+            tpb = (tpb + p.nwaves - 1) / p.nwaves * p.nwaves;
+            p.tiles_per_block = tpb;
+            p.queries = reinterpret_cast<const FzQuery *>(c->d_qbuf + o_q) + first;
+            p.qblob = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_peq);
+            p.qtok_id = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_id);
+            p.qtok_pos = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_pos);
+            p.qtok_len1 = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_len);
+            p.scores = c->d_scores; p.row_stride = row_stride;
+            p.ties = g_ties_norm_distance;
+            HIP_TRY(fz_launch_score(W, p, count, st));
+            c->timing.score_launches++;
+        }
+        HIP_TRY(hipEventRecord(e1, st));
+        score_spans.push_back({ev - 2, ev - 1});
+        c->timing.pairs += (uint64_t)rows * c->n;
+
+        if (topk) {
+            FzSelectParams sp{};
+            sp.scores = c->d_scores; sp.row_stride = row_stride; sp.n = (uint32_t)c->n;
+            sp.orig_of_phys = c->d_orig_of_phys; sp.phys_of_orig = c->d_phys_of_orig;
+            sp.min_score = min_score; sp.k = k; sp.base_index = c->base;
+            sp.out_keys = d_keys + q0 * k; sp.out_cnt = d_cnt ? d_cnt + q0 : nullptr;
+            HIP_TRY(fz_launch_select(sp, rows, st));
+            c->timing.select_launches++;
+            hipEvent_t e2 = get_event(c, ev++);
+            if (!e2) return fail(FZ_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e2, st));
+            select_spans.push_back({ev - 2, ev - 1});
+            ev_last = e2;
+        } else {
+            h_rows.resize((size_t)rows * row_stride);
+            HIP_TRY(hipMemcpyAsync(h_rows.data(), c->d_scores, h_rows.size(), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (uint32_t r = 0; r < rows; ++r) {
+                const uint8_t *src = h_rows.data() + (size_t)r * row_stride;
+                uint8_t *dst = o.scores + (q0 + r) * c->n;
+                for (uint64_t ph = 0; ph < c->n; ++ph) dst[c->h_orig_of_phys[ph]] = src[ph];
+            }
+            ev_last = e1;
+        }
+    }
+
+    if (mode == RUN_TOPK_HOST) {
+        std::vector<uint64_t> h_keys((size_t)nq * k);
+        HIP_TRY(hipMemcpyAsync(h_keys.data(), d_keys, h_keys.size() * 8, hipMemcpyDeviceToHost, st));
+        hipEvent_t e3 = get_event(c, ev++);
+        HIP_TRY(hipEventRecord(e3, st));
+        ev_last = e3;
+        HIP_TRY(hipStreamSynchronize(st));
+        decode_keys(h_keys.data(), nq, k, o.idx, o.score, o.cnt);
+    } else if (mode == RUN_TOPK_DEVICE) {
+        if (!o.sync) return FZ_OK;                  // timings are not collected on the async path
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (auto &s : score_spans) { float ms = 0; if (hipEventElapsedTime(&ms, c->events[s.first], c->events[s.second]) == hipSuccess) c->timing.score_ms += ms; }
+    for (auto &s : select_spans) { float ms = 0; if (hipEventElapsedTime(&ms, c->events[s.first], c->events[s.second]) == hipSuccess) c->timing.select_ms += ms; }
+    if (ev_last) { float ms = 0; if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) c->timing.total_ms = ms; }
+    return FZ_OK;
+}
+
+extern "C" int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                             int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx,
+                             int32_t *out_score, uint32_t *out_cnt)
+{
+    if (nq && k && (!out_idx || !out_score)) return fail(FZ_ERR_INVALID, "null output buffers");
+    RunOut o; o.idx = out_idx; o.score = out_score; o.cnt = out_cnt;
+    return run_queries(c, q_cps, q_offs, nq, scorer, min_score, k, RUN_TOPK_HOST, o);
+}
+
+extern "C" int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs,
+                                  uint32_t nq, int scorer, int32_t min_score, uint32_t k,
+                                  uint64_t *out_keys_device, uint32_t *out_cnt_device, int sync)
+{
+    if (nq && k && !out_keys_device) return fail(FZ_ERR_INVALID, "null device key buffer");
+    RunOut o; o.d_keys = out_keys_device; o.d_cnt = out_cnt_device; o.sync = sync;
+    return run_queries(c, q_cps, q_offs, nq, scorer, min_score, k, RUN_TOPK_DEVICE, o);
+}
+
+extern "C" int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                            int scorer, uint8_t *out_scores)
+{
+    if (nq && c && c->n && !out_scores) return fail(FZ_ERR_INVALID, "null output buffer");
+    RunOut o; o.scores = out_scores;
+    return run_queries(c, q_cps, q_offs, nq, scorer, 0, 0, RUN_SCORE_ALL, o);
+}
+
+// Deterministic merge of per-shard key lists: plain descending sort of the n_lists*k keys of each
+// query.  A key orders by (score desc, global index asc), so the result does not depend on how the
+// corpus was sharded or on the order the lists were gathered in.
+extern "C" int fz_merge_topk(const uint64_t *keys, uint32_t n_lists, uint32_t nq, uint32_t k,
+                             uint64_t *out_idx, int32_t *out_score, uint32_t *out_cnt)
+{
+    if ((uint64_t)n_lists * nq * k && (!keys || !out_idx || !out_score)) return fail(FZ_ERR_INVALID, "null argument");
+    std::vector<uint64_t> tmp, merged((size_t)nq * k, 0ull);
+    for (uint32_t q = 0; q < nq; ++q) {
+        tmp.clear();
+        for (uint32_t l = 0; l < n_lists; ++l)
+            for (uint32_t i = 0; i < k; ++i) {
+                uint64_t key = keys[((uint64_t)l * nq + q) * k + i];
+                if (key) tmp.push_back(key);
+            }
+        std::sort(tmp.begin(), tmp.end(), [](uint64_t a, uint64_t b) { return a > b; });
+        for (uint32_t i = 0; i < k && i < tmp.size(); ++i) merged[(size_t)q * k + i] = tmp[i];
+    }
+    if (nq && k) decode_keys(merged.data(), nq, k, out_idx, out_score, out_cnt);
+    else if (out_cnt) memset(out_cnt, 0, (size_t)nq * 4);
+    return FZ_OK;
+}
+
+extern "C" int fz_distance_batch(int device, int kind, const uint32_t *a_cps, const uint64_t *a_offs,
+                                 const uint32_t *b_cps, const uint64_t *b_offs, uint64_t n_pairs,
+                                 uint32_t *out_dist)
+{
+    (void)device; (void)kind; (void)a_cps; (void)a_offs; (void)b_cps; (void)b_offs; (void)n_pairs; (void)out_dist;
+    return fail(FZ_ERR_INVALID, "fz_distance_batch is not implemented by this build");
+}

@@ -1,0 +1,420 @@
+// fz_kernels.hip -- gfx950 (MI355X, wave64) kernels of libfuzzyhip.so.
+//
+//  fz_score_general<W>  one candidate per lane, one query per blockIdx.y.  Bit-parallel LCS
+//                       (Hyyro) of the query pattern (W 32-bit words, Peq table in LDS) against the
+//                       candidate's canonical symbols, with the token-set intersection applied as
+//                       bit masks on both sides, then the exact integer form of thefuzz's rounded
+//                       ratio.  Writes one u8 score per (query, candidate).
+//  fz_select_topk       one block per query row: threshold, (score desc, original index asc)
+//                       top-k with exact tie handling.
+//
+// Reference semantics: src/fuzzy_search.py:22-38 (loop, threshold, stable sort, slice) and the
+// third-party scorer it calls.  DESIGN.md derives the masks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fuzzyhip.h"
+#include "fz_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// exact rounded ratio: round(100 * (L - d) / L), ties resolved by the host-evaluated table
+// ---------------------------------------------------------------------------------------------
+// thefuzz returns int(round(x)) of x = 100 - 100*d/L (token_set) or (1 - d/L)*100 (ratio), both in
+// fp64.  x differs from the exact rational by ~1e-13 while a non-tie rational is >= 1/(2L) away
+// from any k+0.5, so the fp64 result equals exact rounding except on exact ties, where the fp64
+// evaluation (a function of d/L only) decides; the host evaluates those 100 cases once per formula
+// (fz_host.cpp make_tie_table) and hands them over as a 100-bit table.  Integer-only on the device.
+__device__ __forceinline__ uint32_t fz_round_ratio(uint32_t d, uint32_t L, FzTies ties)
+{
+    uint32_t N = 100u * (L - d);                    // < 2^24 for every supported length
+    float r = __builtin_amdgcn_rcpf((float)L);
+    uint32_t q = (uint32_t)((float)N * r);          // floor(N/L) +- 1
+    int32_t rem = (int32_t)(N - q * L);
+    if (rem < 0) { q -= 1; rem += (int32_t)L; }
+    else if ((uint32_t)rem >= L) { q += 1; rem -= (int32_t)L; }
+    uint32_t twice = 2u * (uint32_t)rem;
+    if (twice > L) {
+        q += 1;
+    } else if (twice == L) {
+        uint64_t t = q < 64 ? (ties.lo >> q) : (ties.hi >> (q - 64));
+        q += (uint32_t)(t & 1ull);
+    }
+    return q;
+}
+
+// token_set_ratio from the integer summary of one (query, candidate) pair.
+//   n_qtok : tokens in the query, m: pattern length = sum(len+1) over query tokens
+//   clen   : canonical candidate length = sum(len+1) over its tokens (0 = no tokens)
+//   nhits  : tokens in the intersection, sect1 = sum(len+1) over them
+//   lcs1   : LCS of (kept pattern, kept text), each with one separator after EVERY kept token; as
+//            both then end in a separator this is LCS(diff_ab_joined, diff_ba_joined) + 1.
+// Follows rapidfuzz fuzz::token_set_ratio: r0 on the joined differences,
+// r1/r2 from the length differences, max, then thefuzz's int(round()).  max(r1, r2) is the one with
+// the shorter difference (both are decreasing in it), so two roundings suffice; rounding is monotone,
+// hence max-then-round == round-then-max.
+__device__ __forceinline__ uint32_t fz_token_set_score(uint32_t n_qtok, uint32_t m, uint32_t clen,
+                                                       uint32_t nhits, uint32_t sect1,
+                                                       uint32_t lcs1, FzTies ties)
+{
+    if (n_qtok == 0u || clen == 0u) return 0u;        // either token list empty -> 0
+    uint32_t PA = m - sect1, TB = clen - sect1;
+    if (nhits != 0u && (PA == 0u || TB == 0u)) return 100u;   // one token set contains the other
+    uint32_t ab = PA - 1u, ba = TB - 1u, lcs = lcs1 - 1u;
+    uint32_t d0 = ab + ba - 2u * lcs;
+    if (nhits == 0u) return fz_round_ratio(d0, ab + ba, ties);
+    uint32_t sl = sect1 - 1u;
+    uint32_t r0 = fz_round_ratio(d0, 2u * sl + 2u + ab + ba, ties);
+    uint32_t mn = ab < ba ? ab : ba;
+    uint32_t r1 = fz_round_ratio(1u + mn, 2u * sl + 1u + mn, ties);
+    return r0 > r1 ? r0 : r1;
+}
+
+// clear bits [s, e) (e > s) of a per-lane bit row stored word-major with stride 64 (row[w*64])
+__device__ __forceinline__ void fz_clear_bits(uint32_t *row, uint32_t s, uint32_t e)
+{
+    uint32_t w0 = s >> 5, w1 = (e - 1u) >> 5;
+    for (uint32_t w = w0; w <= w1; ++w) {
+        uint32_t lo = (w == w0) ? (s & 31u) : 0u;
+        uint32_t hi = (w == w1) ? ((e - 1u) & 31u) + 1u : 32u;
+        uint32_t mask = (hi == 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        row[w * 64u] &= ~mask;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// general scoring kernel: any pattern width W (32-bit words), any candidate length
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t *s_peq = lds;                                    // [alphabet][W]
+    uint32_t *s_qid = s_peq + p.alphabet * W;                 // [pmax] query token ids, ascending
+    uint32_t *s_qpos = s_qid + p.pmax;                        // first pattern bit of the token
+    uint32_t *s_qlen = s_qpos + p.pmax;                       // token length + 1
+    uint32_t *s_M = s_qlen + p.pmax;                          // [nwaves][W][64] pattern keep masks
+    uint32_t *s_TK = s_M + p.nwaves * (uint32_t)W * 64u;      // [nwaves][ntkw][64] text keep masks
+
+    const FzQuery q = p.queries[blockIdx.y];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+    for (uint32_t i = tid; i < p.alphabet * (uint32_t)W; i += blockDim.x) s_peq[i] = p.qblob[q.peq_off + i];
+    for (uint32_t i = tid; i < q.n_ids; i += blockDim.x) {
+        s_qid[i] = p.qtok_id[q.tok_off + i];
+        s_qpos[i] = p.qtok_pos[q.tok_off + i];
+        s_qlen[i] = p.qtok_len1[q.tok_off + i];
+    }
+    __syncthreads();
+
+    uint32_t *Mrow = s_M + wave * (uint32_t)W * 64u + lane;
+    uint32_t *TKrow = s_TK + wave * p.ntkw * 64u + lane;
+    const uint32_t nsteps = q.n_ids ? 32u - (uint32_t)__builtin_clz(q.n_ids) : 0u;
+
+    uint32_t t_end = (blockIdx.x + 1u) * p.tiles_per_block;
+    if (t_end > p.ntiles) t_end = p.ntiles;
+    for (uint32_t tile = blockIdx.x * p.tiles_per_block + wave; tile < t_end; tile += p.nwaves) {
+        const FzTile td = p.tiles[tile];
+        const uint32_t ntkw = ((uint32_t)td.ndw + 7u) >> 3;
+
+#pragma unroll
+        for (int w = 0; w < W; ++w) Mrow[w * 64] = 0xFFFFFFFFu;
+        for (uint32_t t = 0; t < ntkw; ++t) TKrow[t * 64u] = 0xFFFFFFFFu;
+
+        // ---- token intersection: which candidate tokens are query tokens ---------------------
+        uint32_t sect1 = 0u, nhits = 0u, prev_end = 0u;
+        for (uint32_t i = 0; i < td.ntok; ++i) {
+            const uint32_t cid = p.tokid[td.toff + i * 64u + lane];
+            const uint32_t cend = p.tokend[td.toff + i * 64u + lane];
+            uint32_t lo = 0u, hi = q.n_ids;
+            for (uint32_t s = 0; s < nsteps; ++s) {          // lower_bound, uniform trip count
+                if (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (s_qid[mid] < cid) lo = mid + 1u; else hi = mid;
+                }
+            }
+            if (lo < q.n_ids && s_qid[lo] == cid) {
+                const uint32_t pos = s_qpos[lo], len1 = s_qlen[lo];
+                fz_clear_bits(Mrow, pos, pos + len1);         // drop the token from the pattern
+                fz_clear_bits(TKrow, prev_end, cend);         // and from the text
+                sect1 += len1;
+                nhits += 1u;
+            }
+            prev_end = cend;
+        }
+        const uint32_t clen = prev_end;                       // pad slots carry end = length
+
+        uint32_t M[W], V[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { M[w] = Mrow[w * 64]; V[w] = 0xFFFFFFFFu; }
+
+        // ---- bit-parallel LCS over the kept text --------------------------------------------
+        const uint32_t *symp = p.sym + td.coff + lane;
+        uint32_t tkw = 0u;
+        for (uint32_t d = 0; d < td.ndw; ++d) {
+            const uint32_t cw = symp[d * 64u];
+            if ((d & 7u) == 0u) tkw = TKrow[(d >> 3) * 64u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t s = (cw >> (8 * k)) & 0xFFu;
+                if (((tkw >> k) & 1u) == 0u) s = FZ_SYM_NULL;  // removed token: no match, no change
+                const uint32_t *row = s_peq + s * (uint32_t)W;
+                uint32_t carry = 0u;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const uint32_t u = V[w] & row[w] & M[w];
+                    const uint64_t t = (uint64_t)V[w] + (uint64_t)u + (uint64_t)carry;
+                    carry = (uint32_t)(t >> 32);
+                    V[w] = (uint32_t)t | (V[w] ^ u);
+                }
+            }
+            tkw >>= 4;
+        }
+        uint32_t lcs1 = 0u;
+#pragma unroll
+        for (int w = 0; w < W; ++w) lcs1 += (uint32_t)__builtin_popcount(~V[w]);
+
+        const uint32_t sc = fz_token_set_score(q.n_tok, q.m, clen, nhits, sect1, lcs1, p.ties);
+        p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// top-k selection
+// ---------------------------------------------------------------------------------------------
+#define SEL_THREADS 256u
+#define SEL_TIECAP 2048u
+
+__device__ __forceinline__ uint64_t fz_local_key(uint32_t score, uint32_t orig)
+{
+    return ((uint64_t)score << 32) | (uint64_t)(0xFFFFFFFFu - orig);
+}
+
+// block-wide suffix sums of the 128-bin histogram; afterwards s_cum[t] = #scores >= t (t < 128),
+// s_cum[128] = 0, and s_tlow is raised to the largest t that still has >= k scores at or above it.
+__device__ __forceinline__ void fz_sel_update(uint32_t *s_hist, uint32_t *s_cum, uint32_t *s_misc,
+                                              uint32_t k)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    __syncthreads();
+    uint32_t v = 0u;
+    if (tid < 128u) {
+        v = s_hist[tid];
+        for (uint32_t off = 1u; off < 64u; off <<= 1) {
+            uint32_t t = __shfl_down(v, off, 64);
+            if (lane + off < 64u) v += t;
+        }
+        if (tid == 64u) s_misc[1] = v;                        // total of bins 64..127
+    }
+    __syncthreads();
+    if (tid < 128u) {
+        if (tid < 64u) v += s_misc[1];
+        s_cum[tid] = v;
+    }
+    if (tid == 128u) s_cum[128] = 0u;
+    __syncthreads();
+    if (tid < 128u) {
+        if (s_cum[tid] >= k && s_cum[tid + 1u] < k && tid > s_misc[0]) s_misc[0] = tid;
+    }
+    __syncthreads();
+}
+
+template <typename T, bool DESC>
+__device__ __forceinline__ void fz_bitonic(T *a, uint32_t P)
+{
+    for (uint32_t k2 = 2u; k2 <= P; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0u; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    bool up = ((i & k2) == 0u);
+                    T x = a[i], y = a[ixj];
+                    bool sw = DESC ? (up ? (x < y) : (x > y)) : (up ? (x > y) : (x < y));
+                    if (sw) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
+{
+    __shared__ uint32_t s_hist[128];
+    __shared__ uint32_t s_cum[129];
+    __shared__ uint32_t s_misc[8];          // 0: tlow  1: scratch  2: n_gt  3: n_tie  4..7: wave counts
+    __shared__ uint64_t s_keys[FZ_MAX_K];
+    __shared__ uint32_t s_ties[SEL_TIECAP];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t row = blockIdx.x, n = p.n, k = p.k;
+    const uint8_t *sc = p.scores + (uint64_t)row * p.row_stride;
+    const uint32_t min_score = p.min_score < 0 ? 0u : (uint32_t)p.min_score;
+
+    if (tid < 128u) s_hist[tid] = 0u;
+    if (tid == 0u) { s_misc[0] = min_score; s_misc[2] = 0u; s_misc[3] = 0u; }
+    __syncthreads();
+
+    // ---- pass A: histogram of the scores that can still matter ------------------------------
+    const uint32_t per_iter = SEL_THREADS * 16u;
+    const uint32_t niter = (n + per_iter - 1u) / per_iter;
+    for (uint32_t it = 0; it < niter; ++it) {
+        const uint32_t base = (it * SEL_THREADS + tid) * 16u;
+        if (base < n) {
+            const uint32_t tlow = s_misc[0];
+            const uint4 v = *reinterpret_cast<const uint4 *>(sc + base);
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;
+                    if (s >= tlow && base + (uint32_t)(4 * a + b) < n) atomicAdd(&s_hist[s & 127u], 1u);
+                }
+            }
+        }
+        if ((it & 7u) == 7u) fz_sel_update(s_hist, s_cum, s_misc, k);
+    }
+    fz_sel_update(s_hist, s_cum, s_misc, k);
+
+    const uint32_t sstar = s_misc[0];                    // k-th best score (or min_score)
+    const uint32_t n_gt = s_cum[sstar + 1u];             // strictly better: all of them are results
+    const uint32_t c_eq = s_hist[sstar];                 // ties at the cut
+    uint32_t need = k - n_gt;                            // n_gt < k by construction
+    if (need > c_eq) need = c_eq;
+    const bool few_ties = c_eq <= SEL_TIECAP;
+
+    // ---- pass B: collect ----------------------------------------------------------------------
+    for (uint32_t it = 0; it < niter; ++it) {
+        const uint32_t base = (it * SEL_THREADS + tid) * 16u;
+        if (base < n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(sc + base);
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;
+                    const uint32_t ph = base + (uint32_t)(4 * a + b);
+                    if (ph < n && s >= sstar) {
+                        if (s > sstar) {
+                            uint32_t pos = atomicAdd(&s_misc[2], 1u);
+                            s_keys[pos] = fz_local_key(s, p.orig_of_phys[ph]);
+                        } else if (few_ties && need > 0u) {
+                            uint32_t pos = atomicAdd(&s_misc[3], 1u);
+                            s_ties[pos] = p.orig_of_phys[ph];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- ties at the cut: the `need` smallest original indices ------------------------------
+    if (need > 0u) {
+        if (few_ties) {
+            if (need < c_eq) {
+                uint32_t P = 2u;
+                while (P < c_eq) P <<= 1;
+                for (uint32_t i = c_eq + tid; i < P; i += blockDim.x) s_ties[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                fz_bitonic<uint32_t, false>(s_ties, P);
+            }
+        } else {
+            // many ties: walk candidates in ORIGINAL order and keep the first `need` tied ones
+            uint32_t found = 0u;
+            for (uint32_t o0 = 0u; o0 < n && found < need; o0 += SEL_THREADS) {
+                const uint32_t o = o0 + tid;
+                bool pred = false;
+                if (o < n) pred = (sc[p.phys_of_orig[o]] == (uint8_t)sstar);
+                const uint64_t bal = __ballot(pred);
+                if (lane == 0u) s_misc[4 + wave] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                uint32_t before = found;
+                for (uint32_t w = 0; w < wave; ++w) before += s_misc[4 + w];
+                const uint32_t mine = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (pred && mine < need) s_ties[mine] = o;
+                found += s_misc[4] + s_misc[5] + s_misc[6] + s_misc[7];
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = tid; i < need; i += blockDim.x) s_keys[n_gt + i] = fz_local_key(sstar, s_ties[i]);
+    }
+    const uint32_t total = n_gt + need;
+    uint32_t P = 2u;
+    while (P < total) P <<= 1;
+    __syncthreads();
+    for (uint32_t i = total + tid; i < P; i += blockDim.x) s_keys[i] = 0ull;
+    __syncthreads();
+    fz_bitonic<uint64_t, true>(s_keys, P);
+
+    for (uint32_t i = tid; i < k; i += blockDim.x) {
+        uint64_t out = 0ull;
+        if (i < total) {
+            const uint64_t key = s_keys[i];
+            const uint64_t score = key >> 32;
+            const uint64_t gidx = p.base_index + (uint64_t)(0xFFFFFFFFu - (uint32_t)key);
+            out = (score << FZ_IDX_BITS) | (FZ_IDX_MASK - gidx);
+        }
+        p.out_keys[(uint64_t)row * k + i] = out;
+    }
+    if (p.out_cnt != nullptr && tid == 0u) p.out_cnt[row] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers (called from fz_host.cpp)
+// ---------------------------------------------------------------------------------------------
+static const int kGeneralWidths[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+
+int fz_pick_width(uint32_t m)
+{
+    uint32_t need = (m + 31u) / 32u;
+    if (need == 0u) need = 1u;
+    for (int w : kGeneralWidths)
+        if ((uint32_t)w >= need) return w;
+    return -1;
+}
+
+size_t fz_score_lds_bytes(int W, const FzScoreParams &p)
+{
+    return 4ull * ((size_t)p.alphabet * W + 3ull * p.pmax + (size_t)p.nwaves * 64ull * ((size_t)W + p.ntkw));
+}
+
+template <int W>
+static hipError_t launch_general(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_general<W>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fz_score_general<W>, grid, dim3(p.nwaves * 64u), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t fz_launch_score(int W, const FzScoreParams &p, uint32_t nq, hipStream_t st)
+{
+    if (nq == 0u || p.ntiles == 0u) return hipSuccess;
+    dim3 grid((p.ntiles + p.tiles_per_block - 1u) / p.tiles_per_block, nq);
+    size_t lds = fz_score_lds_bytes(W, p);
+    switch (W) {
+    case 1: return launch_general<1>(p, grid, lds, st);
+    case 2: return launch_general<2>(p, grid, lds, st);
+    case 3: return launch_general<3>(p, grid, lds, st);
+    case 4: return launch_general<4>(p, grid, lds, st);
+    case 6: return launch_general<6>(p, grid, lds, st);
+    case 8: return launch_general<8>(p, grid, lds, st);
+    case 12: return launch_general<12>(p, grid, lds, st);
+    case 16: return launch_general<16>(p, grid, lds, st);
+    case 24: return launch_general<24>(p, grid, lds, st);
+    case 32: return launch_general<32>(p, grid, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st)
+{
+    if (rows == 0u || p.k == 0u) return hipSuccess;
+    hipLaunchKernelGGL(fz_select_topk, dim3(rows), dim3(SEL_THREADS), 0, st, p);
+    return hipGetLastError();
+}
