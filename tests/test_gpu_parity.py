@@ -91,3 +91,83 @@ def test_fuzzysearch_dropin(oracle):
     many = fs.find_best_matches_many(["coke zero", "fanta"], "product")
     assert many[0] == fs.find_best_matches("coke zero", "product")
     fs.close()
+
+
+def test_golden_pairs_on_gpu():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pairs.json")) as f:
+        recs = json.load(f)
+    cands = [r["c"] for r in recs]
+    with Corpus.from_prepared(cands) as c:
+        for lo in range(0, len(recs), 64):
+            chunk = recs[lo:lo + 64]
+            got = c.score_all([r["q"] for r in chunk])
+            for j, r in enumerate(chunk):
+                assert int(got[j, lo + j]) == r["token_set"], r
+
+
+def test_full_size_properties():
+    """C2-sized corpus: properties that need no oracle pass over 10^6 candidates."""
+    n = 1_000_000
+    cps, offs = synth.make_corpus(n, max_chars=64)
+    queries = synth.make_queries(cps, offs, 48)
+    picks = [0, 17, n // 2, n - 1]
+    exact = synth.to_strings(cps, offs, 0, 18) + synth.to_strings(cps, offs, n // 2, n // 2 + 1) + synth.to_strings(cps, offs, n - 1, n)
+    exact = [exact[0], exact[17], exact[18], exact[19]]
+    k = 10
+    with Corpus(cps, offs) as c:
+        idx, score, cnt = c.topk(queries + exact, 35, k)
+        # (1) a candidate queried by its own text scores 100; rows sorted by (score desc, index asc)
+        for j in range(4):
+            row = len(queries) + j
+            assert score[row, 0] == 100
+        for r in range(idx.shape[0]):
+            keys = [(-int(score[r, j]), int(idx[r, j])) for j in range(int(cnt[r]))]
+            assert keys == sorted(keys) and len(set(keys)) == len(keys)
+        # (2) token order and repetition in the query do not matter (token SET)
+        shuffled = [" ".join(reversed(q.split())) + " " + q.split()[0] if q else q for q in queries]
+        idx2, score2, cnt2 = c.topk(shuffled, 35, k)
+        assert (idx2 == idx[:len(queries)]).all() and (score2 == score[:len(queries)]).all()
+        # (3) sharding invariance: top-k of the whole == merge of the top-k of two halves
+        full_keys = None
+    half = n // 2
+    from tts_amd import merge_topk
+    lists = np.zeros((2, len(queries), k), dtype=np.uint64)
+    for s, (lo, hi) in enumerate(((0, half), (half, n))):
+        sub_offs = offs[lo:hi + 1] - offs[lo]
+        sub_cps = cps[int(offs[lo]):int(offs[hi])]
+        with Corpus(sub_cps, sub_offs, base_index=lo) as c:
+            i3, s3, c3 = c.topk(queries, 35, k)
+            for q in range(len(queries)):
+                for j in range(int(c3[q])):
+                    lists[s, q, j] = (int(s3[q, j]) << 40) | (((1 << 40) - 1) - int(i3[q, j]))
+    mi, ms, mc = merge_topk(lists, 2, len(queries), k)
+    assert (mi == idx[:len(queries)]).all() and (ms == score[:len(queries)]).all()
+
+
+def _sharded_worker(rank, world, port, ret):
+    import os, sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tts_amd.sharded import ShardedFuzzySearch
+    cps, offs = synth.make_corpus(4001, max_chars=48, seed=21, vocab_size=40)
+    items = [s.upper() if i % 3 == 0 else s for i, s in enumerate(synth.to_strings(cps, offs))]
+    queries = synth.make_queries(cps, offs, 9, seed=22, max_chars=48)
+    fs = ShardedFuzzySearch(items, items[:50], threshold=0.35, device=0)
+    got = fs.find_best_matches_many(queries, "product")
+    single = FuzzySearch(items, items[:50], threshold=0.35)
+    exp = single.find_best_matches_many(queries, "product")
+    ret[rank] = (got == exp)
+    fs.close(); single.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_one_gpu():
+    """2 ranks sharing the one GPU, gloo for the exchange: sharded result == single-shard result."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_sharded_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
