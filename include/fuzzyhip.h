@@ -155,6 +155,17 @@ int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, ui
                  int scorer, uint8_t *out_scores);
 
 /*
+ * fz_distance_all -- raw distances of nq queries against every candidate AS GIVEN (no token
+ * canonicalisation), ORIGINAL candidate order: out_dist[q*n + i], host memory, u16.
+ *   kind 0: InDel distance  
+ *   kind 1: uniform-cost Levenshtein by the Myers/Hyyro Pv/Mv bit-vector recurrence; this is
+ *           AdvancedFuzzyMatcher.levenshtein_distance of reference app.py:296-317 once the host has
+ *           applied its normalize_text (app.py:271-273) to both sides
+ */
+int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                    int kind, uint16_t *out_dist);
+
+/*
  * fz_distance_batch -- raw distances of n_pairs explicit (a_i, b_i) string pairs, computed by the
  * same bit-parallel device routines the scorers use.
  *   kind 0: InDel distance |a|+|b|-2*LCS (what thefuzz's ratios normalise)

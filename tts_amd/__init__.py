@@ -2,7 +2,7 @@
 ``src/fuzzy_search.py``.  ``FuzzySearch`` is the drop-in class; ``Corpus`` the
 handle-level API over ``libfuzzyhip.so``."""
 from .config import FUZZY_SEARCH_THRESHOLD_FLOAT, TOP_N_MATCHES_INT
-from .corpus import Corpus, merge_topk
+from .corpus import Corpus, distance_batch, merge_topk
 from .fuzzy_search import FuzzySearch
 
-__all__ = ["FuzzySearch", "Corpus", "merge_topk", "TOP_N_MATCHES_INT", "FUZZY_SEARCH_THRESHOLD_FLOAT"]
+__all__ = ["FuzzySearch", "Corpus", "merge_topk", "distance_batch", "TOP_N_MATCHES_INT", "FUZZY_SEARCH_THRESHOLD_FLOAT"]

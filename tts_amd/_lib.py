@@ -56,6 +56,8 @@ _SIGNATURES = {
     "fz_merge_topk": (ctypes.c_int, [c_u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_u64p,
                                      c_i32p, c_u32p]),
     "fz_score_all": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int, c_u8p]),
+    "fz_distance_all": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_uint16)]),
     "fz_distance_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_u32p, c_u64p, c_u32p, c_u64p,
                                          ctypes.c_uint64, c_u32p]),
     "fz_last_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(FzTiming)]),

@@ -117,6 +117,15 @@ class Corpus:
                                           out.ctypes.data_as(_lib.c_u8p)))
         return out[:nq, :self.n]
 
+    def distance_all(self, queries, kind: int = 0) -> np.ndarray:
+        """Raw distances against every candidate as given (no canonicalisation), original order:
+        uint16 [nq, n].  kind 0 = InDel, 1 = Levenshtein (Myers bit-vector kernel)."""
+        q_cps, q_offs, nq = self._pack_queries(queries)
+        out = np.zeros((max(nq, 1), max(self.n, 1)), dtype=np.uint16)
+        _lib.check(self._lib.fz_distance_all(self._handle(), _u32(q_cps), _u64(q_offs), nq, int(kind),
+                                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16))))
+        return out[:nq, :self.n]
+
     # -- introspection -------------------------------------------------------------------------
     def info(self) -> dict:
         inf = _lib.FzInfo()
@@ -133,6 +142,19 @@ class Corpus:
 
     def set_workspace_limit(self, nbytes: int) -> None:
         _lib.check(self._lib.fz_set_workspace_limit(self._handle(), int(nbytes)))
+
+
+def distance_batch(a: Sequence[str], b: Sequence[str], kind: int = 0, device: int = 0) -> np.ndarray:
+    """Distances of explicit pairs (a[i], b[i]) through ``fz_distance_batch``: uint32 [n]."""
+    if len(a) != len(b):
+        raise ValueError("a and b must pair up")
+    lib = _lib.load()
+    a_cps, a_offs = pack_prepared(list(a))
+    b_cps, b_offs = pack_prepared(list(b))
+    out = np.zeros(max(len(a), 1), dtype=np.uint32)
+    _lib.check(lib.fz_distance_batch(int(device), int(kind), _u32(a_cps), _u64(a_offs), _u32(b_cps),
+                                     _u64(b_offs), len(a), _u32(out)))
+    return out[:len(a)]
 
 
 def merge_topk(keys: np.ndarray, n_lists: int, nq: int, k: int):

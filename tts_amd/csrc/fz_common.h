@@ -7,6 +7,10 @@
 #define FZ_SYM_NULL 0u       // padding symbol: its Peq row is all zero, so it never changes the state
 #define FZ_SYM_SPACE 1u      // token separator
 #define FZ_TOK_NONE 0xFFFFFFFFu
+#define FZ_MODE_TOKEN_SET 0
+#define FZ_MODE_RATIO 1
+#define FZ_MODE_INDEL 2
+#define FZ_MODE_LEV 3
 #define FZ_IDX_BITS 40
 #define FZ_IDX_MASK ((1ull << FZ_IDX_BITS) - 1ull)
 

@@ -24,7 +24,7 @@
 // from fz_kernels.hip
 int fz_pick_width(uint32_t m);
 size_t fz_score_lds_bytes(int W, const FzScoreParams &p);
-hipError_t fz_launch_score(int W, const FzScoreParams &p, uint32_t nq, hipStream_t st);
+hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq, hipStream_t st);
 hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
@@ -96,24 +96,32 @@ struct TokHash {
 };
 
 // ---------------------------------------------------------------------------------------------
-// corpus
+// corpus = host dictionaries + up to three device "views" of the same candidate list
 // ---------------------------------------------------------------------------------------------
-struct fz_corpus {
-    int device = 0;
-    uint64_t base = 0, n = 0;
+enum { VIEW_SET = 0,    // sorted unique tokens, each followed by a separator  (token_set_ratio)
+       VIEW_SORT = 1,   // sorted tokens joined by single spaces, repeats kept   (token_sort_ratio)
+       VIEW_RAW = 2,    // the string as given                                   (ratio, distances)
+       N_VIEWS = 3 };
+
+struct View {
+    bool built = false;
     uint32_t npad = 0, ntiles = 0, max_ndw = 0, max_len = 0, max_tok = 0, alphabet = 2;
     uint64_t total_symbols = 0, total_tokens = 0, device_bytes = 0;
-
-    // host-side dictionaries the query preparation needs
     std::vector<uint8_t> sym_of_cp;                       // code point -> symbol (0 = not in corpus)
-    std::deque<std::u32string> vocab_store;               // stable storage of the token strings
-    std::unordered_map<Tok, uint32_t, TokHash> vocab;     // token -> id
-
-    // device corpus
     uint32_t *d_sym = nullptr, *d_tokid = nullptr, *d_orig_of_phys = nullptr, *d_phys_of_orig = nullptr;
     uint16_t *d_tokend = nullptr;
     FzTile *d_tiles = nullptr;
     std::vector<uint32_t> h_orig_of_phys;
+};
+
+struct fz_corpus {
+    int device = 0;
+    uint64_t base = 0, n = 0;
+    std::vector<uint32_t> h_cps;                          // the input, kept for views built on demand
+    std::vector<uint64_t> h_offs;
+    std::deque<std::u32string> vocab_store;               // stable storage of the token strings
+    std::unordered_map<Tok, uint32_t, TokHash> vocab;     // token -> id (VIEW_SET)
+    View views[N_VIEWS];
 
     // query-time state
     hipStream_t stream = nullptr, own_stream = nullptr;
@@ -179,141 +187,152 @@ extern "C" int fz_device_count(int *out_n)
     return FZ_OK;
 }
 
+static void free_view(View &v)
+{
+    for (void *p : {(void *)v.d_sym, (void *)v.d_tokid, (void *)v.d_tokend, (void *)v.d_tiles,
+                    (void *)v.d_orig_of_phys, (void *)v.d_phys_of_orig})
+        if (p) (void)hipFree(p);
+    v = View();
+}
+
 extern "C" void fz_corpus_destroy(fz_corpus *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    for (void *p : {(void *)c->d_sym, (void *)c->d_tokid, (void *)c->d_tokend, (void *)c->d_tiles,
-                    (void *)c->d_orig_of_phys, (void *)c->d_phys_of_orig, (void *)c->d_scores,
-                    (void *)c->d_qbuf, (void *)c->d_keys, (void *)c->d_cnt})
+    for (View &v : c->views) free_view(v);
+    for (void *p : {(void *)c->d_scores, (void *)c->d_qbuf, (void *)c->d_keys, (void *)c->d_cnt})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
-extern "C" int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
-                                uint64_t base_index, fz_corpus **out)
+// Builds one device view: reduce every candidate to the text its scorer compares, map code points
+// to 8-bit symbols, sort by (symbol dwords, tokens, original index), cut into 64-candidate tiles,
+// transpose to symbol-major order and upload.
+static int build_view(fz_corpus *c, int kind)
 {
-    if (!out) return fail(FZ_ERR_INVALID, "out is null");
-    *out = nullptr;
-    if (n && (!cps || !offs)) return fail(FZ_ERR_INVALID, "cps/offs null with n > 0");
-    if (n >= 0xFFFFFFFFull - 64) return fail(FZ_ERR_LIMIT, "shard holds %llu candidates; limit is 2^32-65 per shard", (unsigned long long)n);
-    if (base_index + n > FZ_IDX_MASK) return fail(FZ_ERR_LIMIT, "global index beyond 2^40");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(FZ_ERR_NO_DEVICE, "no HIP device visible: libfuzzyhip has no CPU path");
-    if (device < 0 || device >= ndev) return fail(FZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
-    HIP_TRY(hipSetDevice(device));
-    std::call_once(g_ties_once, make_tie_tables);
+    View &v = c->views[kind];
+    if (v.built) return FZ_OK;
+    const uint64_t n = c->n;
+    const uint32_t *cps = c->h_cps.data();
+    const uint64_t *offs = c->h_offs.data();
 
-    fz_corpus *c = new fz_corpus();
-    c->device = device; c->base = base_index; c->n = n;
-    auto bail = [&](int code) { fz_corpus_destroy(c); return code; };
-
-    // ---- alphabet: every non-separator code point in the input gets an 8-bit symbol ------------
+    // ---- alphabet ---------------------------------------------------------------------------
     {
         std::vector<uint8_t> seen(0x110000, 0);
         const uint64_t total = n ? offs[n] : 0;
-        for (uint64_t i = n ? offs[0] : 0; i < total; ++i) {
-            uint32_t cp = cps[i];
-            if (cp >= 0x110000u) return bail(fail(FZ_ERR_INVALID, "code point 0x%x out of range at %llu", cp, (unsigned long long)i));
-            seen[cp] = 1;
-        }
-        c->sym_of_cp.assign(0x110000, 0);
+        for (uint64_t i = n ? offs[0] : 0; i < total; ++i) seen[cps[i]] = 1;
+        v.sym_of_cp.assign(0x110000, 0);
         uint32_t next = 2;
+        if (kind == VIEW_SORT) v.sym_of_cp[0x20] = (uint8_t)FZ_SYM_SPACE;
         for (uint32_t cp = 0; cp < 0x110000u; ++cp) {
-            if (!seen[cp] || is_space(cp)) continue;
-            if (next > 255u) return bail(fail(FZ_ERR_ALPHABET, "corpus has more than 254 distinct code points; the 8-bit symbol table is full"));
-            c->sym_of_cp[cp] = (uint8_t)next++;
+            if (!seen[cp]) continue;
+            if (kind != VIEW_RAW && is_space(cp)) continue;       // separators never reach the text
+            if (next > 255u) return fail(FZ_ERR_ALPHABET, "corpus has more than 254 distinct code points; the 8-bit symbol table is full");
+            v.sym_of_cp[cp] = (uint8_t)next++;
         }
-        c->alphabet = next;
+        v.alphabet = next;
     }
 
-    // ---- canonical form of every candidate: sorted unique tokens, each followed by a separator --
+    // ---- text of every candidate ------------------------------------------------------------
     std::vector<uint8_t> canon;          // symbols, all candidates back to back
     std::vector<uint64_t> canon_off(n + 1, 0);
-    std::vector<uint32_t> tok_id;        // token ids, all candidates back to back
-    std::vector<uint16_t> tok_end;       // exclusive end (incl. separator) of each token
+    std::vector<uint32_t> tok_id;        // VIEW_SET: token ids, all candidates back to back
+    std::vector<uint16_t> tok_end;       // VIEW_SET: exclusive end (incl. separator) of each token
     std::vector<uint64_t> tok_off(n + 1, 0);
     {
         std::vector<Tok> toks;
         for (uint64_t i = 0; i < n; ++i) {
-            if (offs[i + 1] < offs[i]) return bail(fail(FZ_ERR_INVALID, "offsets not monotone at %llu", (unsigned long long)i));
-            split_sorted(cps + offs[i], offs[i + 1] - offs[i], true, toks);
+            const uint32_t *s = cps + offs[i];
+            const uint64_t sl = offs[i + 1] - offs[i];
             uint64_t len = 0;
-            for (Tok t : toks) {
-                auto it = c->vocab.find(t);
-                uint32_t id;
-                if (it == c->vocab.end()) {
-                    if (c->vocab.size() >= 0xFFFFFFF0ull) return bail(fail(FZ_ERR_LIMIT, "vocabulary exceeds 2^32 tokens"));
-                    c->vocab_store.emplace_back(t);
-                    id = (uint32_t)c->vocab.size();
-                    c->vocab.emplace(Tok(c->vocab_store.back()), id);
-                } else {
-                    id = it->second;
+            if (kind == VIEW_RAW) {
+                for (uint64_t j = 0; j < sl; ++j) canon.push_back(v.sym_of_cp[s[j]]);
+                len = sl;
+                v.total_symbols += len;
+            } else {
+                split_sorted(s, sl, kind == VIEW_SET, toks);
+                for (size_t ti = 0; ti < toks.size(); ++ti) {
+                    Tok t = toks[ti];
+                    if (kind == VIEW_SORT && ti) { canon.push_back((uint8_t)FZ_SYM_SPACE); ++len; }
+                    for (char32_t ch : t) canon.push_back(v.sym_of_cp[(uint32_t)ch]);
+                    len += t.size();
+                    if (kind == VIEW_SET) {
+                        auto it = c->vocab.find(t);
+                        uint32_t id;
+                        if (it == c->vocab.end()) {
+                            if (c->vocab.size() >= 0xFFFFFFF0ull) return fail(FZ_ERR_LIMIT, "vocabulary exceeds 2^32 tokens");
+                            c->vocab_store.emplace_back(t);
+                            id = (uint32_t)c->vocab.size();
+                            c->vocab.emplace(Tok(c->vocab_store.back()), id);
+                        } else {
+                            id = it->second;
+                        }
+                        canon.push_back((uint8_t)FZ_SYM_SPACE);
+                        len += 1;
+                        tok_id.push_back(id);
+                        tok_end.push_back((uint16_t)std::min<uint64_t>(len, 0xFFFF));
+                    }
                 }
-                for (char32_t ch : t) canon.push_back(c->sym_of_cp[(uint32_t)ch]);
-                canon.push_back((uint8_t)FZ_SYM_SPACE);
-                len += t.size() + 1;
-                if (len > FZ_MAX_CAND_LEN) return bail(fail(FZ_ERR_TOO_LONG, "candidate %llu is longer than %u code points", (unsigned long long)i, FZ_MAX_CAND_LEN));
-                tok_id.push_back(id);
-                tok_end.push_back((uint16_t)len);
+                v.total_symbols += (kind == VIEW_SET && len) ? len - 1 : len;
+                v.total_tokens += toks.size();
+                v.max_tok = std::max<uint32_t>(v.max_tok, (uint32_t)toks.size());
             }
+            if (len > FZ_MAX_CAND_LEN) return fail(FZ_ERR_TOO_LONG, "candidate %llu is longer than %u code points", (unsigned long long)i, FZ_MAX_CAND_LEN);
+            if (kind != VIEW_SET) { tok_id.push_back(FZ_TOK_NONE); tok_end.push_back((uint16_t)len); }   // one slot: the length
             canon_off[i + 1] = canon.size();
             tok_off[i + 1] = tok_id.size();
-            c->total_symbols += len ? len - 1 : 0;
-            c->total_tokens += toks.size();
-            c->max_len = std::max<uint32_t>(c->max_len, (uint32_t)len);
-            c->max_tok = std::max<uint32_t>(c->max_tok, (uint32_t)toks.size());
+            v.max_len = std::max<uint32_t>(v.max_len, (uint32_t)len);
         }
     }
 
-    // ---- physical order: sort by (symbol dwords, tokens, original index); tiles of 64 ----------
-    c->ntiles = (uint32_t)((n + FZ_TILE - 1) / FZ_TILE);
-    c->npad = c->ntiles * FZ_TILE;
+    // ---- physical order and tiles -----------------------------------------------------------
+    v.ntiles = (uint32_t)((n + FZ_TILE - 1) / FZ_TILE);
+    v.npad = v.ntiles * FZ_TILE;
     std::vector<uint64_t> keys(n);
     for (uint64_t i = 0; i < n; ++i) {
         uint64_t ndw = (canon_off[i + 1] - canon_off[i] + 3) / 4, nt = tok_off[i + 1] - tok_off[i];
-        keys[i] = (ndw << 48) | (nt << 32) | i;
+        keys[i] = (ndw << 48) | (std::min<uint64_t>(nt, 0xFFFF) << 32) | i;
     }
     std::sort(keys.begin(), keys.end());
-    c->h_orig_of_phys.assign(c->npad, 0xFFFFFFFFu);
+    v.h_orig_of_phys.assign(v.npad, 0xFFFFFFFFu);
     std::vector<uint32_t> phys_of_orig(n);
     for (uint64_t ph = 0; ph < n; ++ph) {
         uint32_t o = (uint32_t)(keys[ph] & 0xFFFFFFFFull);
-        c->h_orig_of_phys[ph] = o;
+        v.h_orig_of_phys[ph] = o;
         phys_of_orig[o] = (uint32_t)ph;
     }
-    std::vector<FzTile> tiles(c->ntiles);
+    std::vector<FzTile> tiles(v.ntiles);
     uint64_t sym_words = 0, tok_slots = 0;
-    for (uint32_t t = 0; t < c->ntiles; ++t) {
+    for (uint32_t t = 0; t < v.ntiles; ++t) {
         uint32_t ndw = 0, ntok = 0;
         for (uint32_t l = 0; l < FZ_TILE; ++l) {
             uint64_t ph = (uint64_t)t * FZ_TILE + l;
             if (ph >= n) break;
-            uint32_t o = c->h_orig_of_phys[ph];
+            uint32_t o = v.h_orig_of_phys[ph];
             ndw = std::max<uint32_t>(ndw, (uint32_t)((canon_off[o + 1] - canon_off[o] + 3) / 4));
             ntok = std::max<uint32_t>(ntok, (uint32_t)(tok_off[o + 1] - tok_off[o]));
         }
+        if (ntok > 0xFFFFu) return fail(FZ_ERR_LIMIT, "a candidate has more than 65535 tokens");
         if (sym_words + (uint64_t)ndw * 64 > 0xFFFFFFFFull || tok_slots + (uint64_t)ntok * 64 > 0xFFFFFFFFull)
-            return bail(fail(FZ_ERR_LIMIT, "shard too large for 32-bit tile offsets; use more shards"));
+            return fail(FZ_ERR_LIMIT, "shard too large for 32-bit tile offsets; use more shards");
         tiles[t].coff = (uint32_t)sym_words; tiles[t].toff = (uint32_t)tok_slots;
         tiles[t].ndw = (uint16_t)ndw; tiles[t].ntok = (uint16_t)ntok;
         sym_words += (uint64_t)ndw * 64; tok_slots += (uint64_t)ntok * 64;
-        c->max_ndw = std::max(c->max_ndw, ndw);
+        v.max_ndw = std::max(v.max_ndw, ndw);
     }
     std::vector<uint32_t> h_sym(sym_words, 0u);
     std::vector<uint32_t> h_tokid(tok_slots, FZ_TOK_NONE);
     std::vector<uint16_t> h_tokend(tok_slots, 0);
-    for (uint32_t t = 0; t < c->ntiles; ++t) {
+    for (uint32_t t = 0; t < v.ntiles; ++t) {
         const FzTile &td = tiles[t];
         for (uint32_t l = 0; l < FZ_TILE; ++l) {
             uint64_t ph = (uint64_t)t * FZ_TILE + l;
             uint32_t len = 0, nt = 0;
             if (ph < n) {
-                uint32_t o = c->h_orig_of_phys[ph];
+                uint32_t o = v.h_orig_of_phys[ph];
                 len = (uint32_t)(canon_off[o + 1] - canon_off[o]);
                 nt = (uint32_t)(tok_off[o + 1] - tok_off[o]);
                 const uint8_t *src = canon.data() + canon_off[o];
@@ -329,26 +348,65 @@ extern "C" int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint6
     }
 
     int rc;
-    if ((rc = upload(&c->d_sym, h_sym, &c->device_bytes)) != FZ_OK) return bail(rc);
-    if ((rc = upload(&c->d_tokid, h_tokid, &c->device_bytes)) != FZ_OK) return bail(rc);
-    if ((rc = upload(&c->d_tokend, h_tokend, &c->device_bytes)) != FZ_OK) return bail(rc);
-    if ((rc = upload(&c->d_tiles, tiles, &c->device_bytes)) != FZ_OK) return bail(rc);
-    if ((rc = upload(&c->d_orig_of_phys, c->h_orig_of_phys, &c->device_bytes)) != FZ_OK) return bail(rc);
-    if ((rc = upload(&c->d_phys_of_orig, phys_of_orig, &c->device_bytes)) != FZ_OK) return bail(rc);
+    if ((rc = upload(&v.d_sym, h_sym, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload(&v.d_tokid, h_tokid, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload(&v.d_tokend, h_tokend, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload(&v.d_tiles, tiles, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload(&v.d_orig_of_phys, v.h_orig_of_phys, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload(&v.d_phys_of_orig, phys_of_orig, &v.device_bytes)) != FZ_OK) return rc;
+    v.built = true;
+    return FZ_OK;
+}
+
+static int corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
+                         uint64_t base_index, int eager_view, fz_corpus **out)
+{
+    if (!out) return fail(FZ_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (n && (!cps || !offs)) return fail(FZ_ERR_INVALID, "cps/offs null with n > 0");
+    if (n >= 0xFFFFFFFFull - 64) return fail(FZ_ERR_LIMIT, "shard holds %llu candidates; limit is 2^32-65 per shard", (unsigned long long)n);
+    if (base_index + n > FZ_IDX_MASK) return fail(FZ_ERR_LIMIT, "global index beyond 2^40");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FZ_ERR_NO_DEVICE, "no HIP device visible: libfuzzyhip has no CPU path");
+    if (device < 0 || device >= ndev) return fail(FZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+    std::call_once(g_ties_once, make_tie_tables);
+    for (uint64_t i = 0; i < n; ++i)
+        if (offs[i + 1] < offs[i]) return fail(FZ_ERR_INVALID, "offsets not monotone at %llu", (unsigned long long)i);
+    const uint64_t lo = n ? offs[0] : 0, hi = n ? offs[n] : 0;
+    for (uint64_t i = lo; i < hi; ++i)
+        if (cps[i] >= 0x110000u) return fail(FZ_ERR_INVALID, "code point 0x%x out of range at %llu", cps[i], (unsigned long long)i);
+
+    fz_corpus *c = new fz_corpus();
+    c->device = device; c->base = base_index; c->n = n;
+    c->h_cps.assign(cps + lo, cps + hi);
+    c->h_offs.resize(n + 1);
+    for (uint64_t i = 0; i <= n; ++i) c->h_offs[i] = n ? offs[i] - lo : 0;
+    int rc = build_view(c, eager_view);
+    if (rc != FZ_OK) { fz_corpus_destroy(c); return rc; }
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) return bail(fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)));
+    if (e != hipSuccess) { fz_corpus_destroy(c); return fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
     *out = c;
     return FZ_OK;
 }
 
+extern "C" int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
+                                uint64_t base_index, fz_corpus **out)
+{
+    return corpus_create(cps, offs, n, device, base_index, VIEW_SET, out);
+}
+
 extern "C" int fz_corpus_info(const fz_corpus *c, fz_info *o)
 {
     if (!c || !o) return fail(FZ_ERR_INVALID, "null argument");
+    const View &v = c->views[VIEW_SET].built ? c->views[VIEW_SET] : c->views[VIEW_RAW];
     o->n = c->n; o->base_index = c->base; o->vocab_size = c->vocab.size();
-    o->alphabet_size = c->alphabet; o->n_tiles = c->ntiles; o->max_len = c->max_len;
-    o->max_tokens = c->max_tok; o->device_bytes = c->device_bytes;
-    o->total_symbols = c->total_symbols; o->total_tokens = c->total_tokens; o->device = c->device;
+    o->alphabet_size = v.alphabet; o->n_tiles = v.ntiles; o->max_len = v.max_len;
+    o->max_tokens = v.max_tok; o->device_bytes = 0;
+    for (const View &w : c->views) o->device_bytes += w.device_bytes;
+    o->total_symbols = v.total_symbols; o->total_tokens = v.total_tokens; o->device = c->device;
     return FZ_OK;
 }
 
@@ -384,41 +442,52 @@ struct QueryBatch {
     std::vector<uint32_t> peq, tok_id, tok_pos, tok_len1;
 };
 
-// Pattern of a query = its sorted unique tokens, each followed by one separator (m code points).
-// Peq[s][w] has bit (i % 32) of word i / 32 set when pattern position i holds symbol s; code points
-// the corpus never uses get no bit anywhere (they can match nothing).  Tokens known to the corpus
-// vocabulary are listed as (id, first bit, len+1), ascending id, for the kernel's binary search.
-static int prepare_query(const fz_corpus *c, const uint32_t *s, uint64_t n, uint32_t out_row,
+// VIEW_SET: pattern = sorted unique tokens, each followed by one separator (m code points); tokens
+// known to the corpus vocabulary are listed as (id, first bit, len+1), ascending id, for the
+// kernel's binary search.  VIEW_SORT: pattern = sorted tokens joined by single spaces.  VIEW_RAW:
+// the query as given.  Peq[s][w] has bit (i % 32) of word i / 32 set when pattern position i holds
+// symbol s; code points the corpus never uses get no bit anywhere (they can match nothing).
+static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64_t n, uint32_t out_row,
                          QueryBatch &b, std::vector<Tok> &toks)
 {
-    split_sorted(s, n, true, toks);
-    uint64_t m = 0;
-    for (Tok t : toks) m += t.size() + 1;
+    const View &v = c->views[kind];
+    std::u32string pat;
+    struct Trip { uint32_t id, pos, len1; };
+    std::vector<Trip> trips;
+    uint32_t ntok = 0;
+    if (kind == VIEW_RAW) {
+        pat.assign(reinterpret_cast<const char32_t *>(s), (size_t)n);
+    } else {
+        split_sorted(s, n, kind == VIEW_SET, toks);
+        ntok = (uint32_t)toks.size();
+        for (size_t ti = 0; ti < toks.size(); ++ti) {
+            Tok t = toks[ti];
+            if (kind == VIEW_SORT && ti) pat.push_back(U' ');
+            if (kind == VIEW_SET) {
+                auto it = c->vocab.find(t);
+                if (it != c->vocab.end()) trips.push_back({it->second, (uint32_t)pat.size(), (uint32_t)t.size() + 1u});
+            }
+            pat.append(t);
+            if (kind == VIEW_SET) pat.push_back(U' ');
+        }
+    }
+    const uint64_t m = pat.size();
     if (m > FZ_MAX_PATTERN) return fail(FZ_ERR_TOO_LONG, "query pattern of %llu code points exceeds FZ_MAX_PATTERN (%u)", (unsigned long long)m, FZ_MAX_PATTERN);
     const int W = fz_pick_width((uint32_t)m);
     FzQuery q{};
     q.peq_off = (uint32_t)b.peq.size();
     q.tok_off = (uint32_t)b.tok_id.size();
-    q.n_tok = (uint32_t)toks.size();
+    q.n_tok = ntok;
     q.m = (uint32_t)m;
     q.out_row = out_row;
-    b.peq.resize(b.peq.size() + (size_t)c->alphabet * W, 0u);
+    b.peq.resize(b.peq.size() + (size_t)v.alphabet * W, 0u);
     uint32_t *peq = b.peq.data() + q.peq_off;
-    struct Trip { uint32_t id, pos, len1; };
-    std::vector<Trip> trips;
-    uint32_t pos = 0;
-    for (Tok t : toks) {
-        for (size_t j = 0; j < t.size(); ++j) {
-            uint32_t cp = (uint32_t)t[j];
-            uint32_t sym = cp < 0x110000u ? c->sym_of_cp[cp] : 0u;
-            uint32_t bit = pos + (uint32_t)j;
-            if (sym) peq[sym * W + (bit >> 5)] |= 1u << (bit & 31u);
-        }
-        uint32_t sep = pos + (uint32_t)t.size();
-        peq[FZ_SYM_SPACE * W + (sep >> 5)] |= 1u << (sep & 31u);
-        auto it = c->vocab.find(t);
-        if (it != c->vocab.end()) trips.push_back({it->second, pos, (uint32_t)t.size() + 1u});
-        pos = sep + 1u;
+    for (uint32_t bit = 0; bit < m; ++bit) {
+        uint32_t cp = (uint32_t)pat[bit];
+        uint32_t sym;
+        if (kind == VIEW_SET && cp == 0x20u) sym = FZ_SYM_SPACE;       // the separators just added
+        else sym = cp < 0x110000u ? v.sym_of_cp[cp] : 0u;
+        if (sym) peq[sym * W + (bit >> 5)] |= 1u << (bit & 31u);
     }
     std::sort(trips.begin(), trips.end(), [](const Trip &a, const Trip &b2) { return a.id < b2.id; });
     q.n_ids = (uint32_t)trips.size();
@@ -448,12 +517,13 @@ static hipEvent_t get_event(fz_corpus *c, size_t i)
     return c->events[i];
 }
 
-enum RunMode { RUN_TOPK_HOST, RUN_TOPK_DEVICE, RUN_SCORE_ALL };
+enum RunMode { RUN_TOPK_HOST, RUN_TOPK_DEVICE, RUN_SCORE_ALL, RUN_DIST_ALL };
 
 struct RunOut {
     uint64_t *idx = nullptr; int32_t *score = nullptr; uint32_t *cnt = nullptr;     // TOPK_HOST
     uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr; int sync = 1;           // TOPK_DEVICE
     uint8_t *scores = nullptr;                                                      // SCORE_ALL
+    uint16_t *dists = nullptr;                                                      // DIST_ALL
 };
 
 static void decode_keys(const uint64_t *keys, uint32_t nq, uint32_t k, uint64_t *idx, int32_t *score, uint32_t *cnt)
@@ -474,25 +544,41 @@ static void decode_keys(const uint64_t *keys, uint32_t nq, uint32_t k, uint64_t 
     }
 }
 
+// scorer -> (view, kernel mode, tie table)
+static int scorer_plan(int scorer, int *view, int *mode, FzTies *ties)
+{
+    switch (scorer) {
+    case FZ_TOKEN_SET: *view = VIEW_SET; *mode = FZ_MODE_TOKEN_SET; *ties = g_ties_norm_distance; return FZ_OK;
+    case FZ_RATIO: *view = VIEW_RAW; *mode = FZ_MODE_RATIO; *ties = g_ties_norm_sim; return FZ_OK;
+    case FZ_TOKEN_SORT: *view = VIEW_SORT; *mode = FZ_MODE_RATIO; *ties = g_ties_norm_sim; return FZ_OK;
+    case FZ_LEVENSHTEIN:
+        return fail(FZ_ERR_INVALID, "FZ_LEVENSHTEIN yields distances, not 0..100 scores: use fz_distance_all / fz_distance_batch");
+    default:
+        return fail(FZ_ERR_INVALID, "scorer %d is not implemented by this build", scorer);
+    }
+}
+
 static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
-                       int scorer, int32_t min_score, uint32_t k, RunMode mode, RunOut &o)
+                       int view_kind, int kmode, FzTies ties, int32_t min_score, uint32_t k,
+                       RunMode mode, RunOut &o)
 {
     if (!c) return fail(FZ_ERR_INVALID, "null corpus");
     if (nq && (!q_offs || (!q_cps && q_offs[nq] != q_offs[0]))) return fail(FZ_ERR_INVALID, "null query buffers");
-    if (scorer != FZ_TOKEN_SET) return fail(FZ_ERR_INVALID, "scorer %d is not implemented by this build", scorer);
-    if (mode != RUN_SCORE_ALL && k > FZ_MAX_K) return fail(FZ_ERR_LIMIT, "k=%u exceeds FZ_MAX_K=%u", k, FZ_MAX_K);
+    const bool topk = mode == RUN_TOPK_HOST || mode == RUN_TOPK_DEVICE;
+    if (topk && k > FZ_MAX_K) return fail(FZ_ERR_LIMIT, "k=%u exceeds FZ_MAX_K=%u", k, FZ_MAX_K);
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = build_view(c, view_kind)) != FZ_OK) return rc;
+    const View &v = c->views[view_kind];
     hipStream_t st = c->stream;
     c->timing = fz_timing{};
 
-    const bool topk = mode != RUN_SCORE_ALL;
     const bool nothing = topk && (k == 0 || c->n == 0 || min_score > 100);
     uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr;
     if (topk && nq && k) {
         if (mode == RUN_TOPK_DEVICE) { d_keys = o.d_keys; d_cnt = o.d_cnt; }
         else {
-            int rc;
             if ((rc = ensure(&c->d_keys, &c->keys_cap, (size_t)nq * k * 8)) != FZ_OK) return rc;
             if ((rc = ensure(&c->d_cnt, &c->cnt_cap, (size_t)nq * 4)) != FZ_OK) return rc;
             d_keys = c->d_keys; d_cnt = c->d_cnt;
@@ -510,13 +596,13 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
         }
         return FZ_OK;
     }
-    if (c->n == 0) return FZ_OK;                                  // SCORE_ALL of an empty corpus
+    if (c->n == 0) return FZ_OK;                                  // *_ALL of an empty corpus
 
-    const uint64_t row_stride = c->npad;
-    uint64_t rows_per_chunk = std::max<uint64_t>(1, c->ws_limit / row_stride);
+    const size_t esz = (mode == RUN_DIST_ALL) ? 2 : 1;            // bytes per (query, candidate) result
+    const uint64_t row_stride = v.npad;                            // in elements
+    uint64_t rows_per_chunk = std::max<uint64_t>(1, c->ws_limit / (row_stride * esz));
     rows_per_chunk = std::min<uint64_t>(rows_per_chunk, nq);
-    int rc;
-    if ((rc = ensure(&c->d_scores, &c->scores_cap, (size_t)(rows_per_chunk * row_stride))) != FZ_OK) return rc;
+    if ((rc = ensure(&c->d_scores, &c->scores_cap, (size_t)(rows_per_chunk * row_stride * esz))) != FZ_OK) return rc;
 
     std::vector<Tok> toks;
     std::vector<uint8_t> h_rows;
@@ -532,7 +618,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
         for (uint32_t r = 0; r < rows; ++r) {
             const uint64_t qi = q0 + r;
             if (q_offs[qi + 1] < q_offs[qi]) return fail(FZ_ERR_INVALID, "query offsets not monotone at %llu", (unsigned long long)qi);
-            rc = prepare_query(c, q_cps + q_offs[qi], q_offs[qi + 1] - q_offs[qi], r, b, toks);
+            rc = prepare_query(c, view_kind, q_cps + q_offs[qi], q_offs[qi + 1] - q_offs[qi], r, b, toks);
             if (rc != FZ_OK) return rc;
         }
         // one device blob: [FzQuery list by class][peq][tok_id][tok_pos][tok_len1]
@@ -565,17 +651,17 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             const int W = l.first;
             const uint32_t first = l.second.first, count = l.second.second;
             FzScoreParams p{};
-            p.sym = c->d_sym; p.tokid = c->d_tokid; p.tokend = c->d_tokend; p.tiles = c->d_tiles;
-            p.ntiles = c->ntiles; p.alphabet = c->alphabet;
+            p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
+            p.ntiles = v.ntiles; p.alphabet = v.alphabet;
             uint32_t pmax = 1;
             for (uint32_t i = 0; i < count; ++i) pmax = std::max(pmax, qlist[first + i].n_ids);
             p.pmax = pmax;
-            p.ntkw = std::max<uint32_t>(1, (c->max_ndw + 7) / 8);
+            p.ntkw = std::max<uint32_t>(1, (v.max_ndw + 7) / 8);
             p.nwaves = 4;
             while (p.nwaves > 1 && fz_score_lds_bytes(W, p) > 64 * 1024) p.nwaves >>= 1;
             if (fz_score_lds_bytes(W, p) > 160 * 1024)
-                return fail(FZ_ERR_TOO_LONG, "pattern width %d words x candidate length %u does not fit in LDS", W, c->max_len);
-            uint64_t work = (uint64_t)c->ntiles * count;
+                return fail(FZ_ERR_TOO_LONG, "pattern width %d words x candidate length %u does not fit in LDS", W, v.max_len);
+            uint64_t work = (uint64_t)v.ntiles * count;
             uint32_t tpb = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(p.nwaves, work / 8192));
             tpb = (tpb + p.nwaves - 1) / p.nwaves * p.nwaves;
             p.tiles_per_block = tpb;
@@ -585,8 +671,8 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             p.qtok_pos = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_pos);
             p.qtok_len1 = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_len);
             p.scores = c->d_scores; p.row_stride = row_stride;
-            p.ties = g_ties_norm_distance;
-            HIP_TRY(fz_launch_score(W, p, count, st));
+            p.ties = ties;
+            HIP_TRY(fz_launch_score(W, kmode, p, count, st));
             c->timing.score_launches++;
         }
         HIP_TRY(hipEventRecord(e1, st));
@@ -596,7 +682,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
         if (topk) {
             FzSelectParams sp{};
             sp.scores = c->d_scores; sp.row_stride = row_stride; sp.n = (uint32_t)c->n;
-            sp.orig_of_phys = c->d_orig_of_phys; sp.phys_of_orig = c->d_phys_of_orig;
+            sp.orig_of_phys = v.d_orig_of_phys; sp.phys_of_orig = v.d_phys_of_orig;
             sp.min_score = min_score; sp.k = k; sp.base_index = c->base;
             sp.out_keys = d_keys + q0 * k; sp.out_cnt = d_cnt ? d_cnt + q0 : nullptr;
             HIP_TRY(fz_launch_select(sp, rows, st));
@@ -607,13 +693,19 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             select_spans.push_back({ev - 2, ev - 1});
             ev_last = e2;
         } else {
-            h_rows.resize((size_t)rows * row_stride);
+            h_rows.resize((size_t)rows * row_stride * esz);
             HIP_TRY(hipMemcpyAsync(h_rows.data(), c->d_scores, h_rows.size(), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             for (uint32_t r = 0; r < rows; ++r) {
-                const uint8_t *src = h_rows.data() + (size_t)r * row_stride;
-                uint8_t *dst = o.scores + (q0 + r) * c->n;
-                for (uint64_t ph = 0; ph < c->n; ++ph) dst[c->h_orig_of_phys[ph]] = src[ph];
+                if (esz == 1) {
+                    const uint8_t *src = h_rows.data() + (size_t)r * row_stride;
+                    uint8_t *dst = o.scores + (q0 + r) * c->n;
+                    for (uint64_t ph = 0; ph < c->n; ++ph) dst[v.h_orig_of_phys[ph]] = src[ph];
+                } else {
+                    const uint16_t *src = reinterpret_cast<const uint16_t *>(h_rows.data()) + (size_t)r * row_stride;
+                    uint16_t *dst = o.dists + (q0 + r) * c->n;
+                    for (uint64_t ph = 0; ph < c->n; ++ph) dst[v.h_orig_of_phys[ph]] = src[ph];
+                }
             }
             ev_last = e1;
         }
@@ -642,8 +734,10 @@ extern "C" int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t
                              int32_t *out_score, uint32_t *out_cnt)
 {
     if (nq && k && (!out_idx || !out_score)) return fail(FZ_ERR_INVALID, "null output buffers");
+    int view, kmode; FzTies ties; int rc;
+    if ((rc = scorer_plan(scorer, &view, &kmode, &ties)) != FZ_OK) return rc;
     RunOut o; o.idx = out_idx; o.score = out_score; o.cnt = out_cnt;
-    return run_queries(c, q_cps, q_offs, nq, scorer, min_score, k, RUN_TOPK_HOST, o);
+    return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_HOST, o);
 }
 
 extern "C" int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs,
@@ -651,16 +745,30 @@ extern "C" int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uin
                                   uint64_t *out_keys_device, uint32_t *out_cnt_device, int sync)
 {
     if (nq && k && !out_keys_device) return fail(FZ_ERR_INVALID, "null device key buffer");
+    int view, kmode; FzTies ties; int rc;
+    if ((rc = scorer_plan(scorer, &view, &kmode, &ties)) != FZ_OK) return rc;
     RunOut o; o.d_keys = out_keys_device; o.d_cnt = out_cnt_device; o.sync = sync;
-    return run_queries(c, q_cps, q_offs, nq, scorer, min_score, k, RUN_TOPK_DEVICE, o);
+    return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_DEVICE, o);
 }
 
 extern "C" int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                             int scorer, uint8_t *out_scores)
 {
     if (nq && c && c->n && !out_scores) return fail(FZ_ERR_INVALID, "null output buffer");
+    int view, kmode; FzTies ties; int rc;
+    if ((rc = scorer_plan(scorer, &view, &kmode, &ties)) != FZ_OK) return rc;
     RunOut o; o.scores = out_scores;
-    return run_queries(c, q_cps, q_offs, nq, scorer, 0, 0, RUN_SCORE_ALL, o);
+    return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, 0, 0, RUN_SCORE_ALL, o);
+}
+
+extern "C" int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                               int kind, uint16_t *out_dist)
+{
+    if (kind != 0 && kind != 1) return fail(FZ_ERR_INVALID, "kind must be 0 (InDel) or 1 (Levenshtein)");
+    if (nq && c && c->n && !out_dist) return fail(FZ_ERR_INVALID, "null output buffer");
+    RunOut o; o.dists = out_dist;
+    return run_queries(c, q_cps, q_offs, nq, VIEW_RAW, kind == 0 ? FZ_MODE_INDEL : FZ_MODE_LEV,
+                       FzTies{0, 0}, 0, 0, RUN_DIST_ALL, o);
 }
 
 // Deterministic merge of per-shard key lists: plain descending sort of the n_lists*k keys of each
@@ -686,10 +794,39 @@ extern "C" int fz_merge_topk(const uint64_t *keys, uint32_t n_lists, uint32_t nq
     return FZ_OK;
 }
 
+// Explicit pairs: group the pairs by their `a` string; each distinct `a` becomes one query against
+// a temporary raw view of its `b` strings, so the distances come out of the very kernels the
+// scorers use (pattern = a, text = b).
 extern "C" int fz_distance_batch(int device, int kind, const uint32_t *a_cps, const uint64_t *a_offs,
                                  const uint32_t *b_cps, const uint64_t *b_offs, uint64_t n_pairs,
                                  uint32_t *out_dist)
 {
-    (void)device; (void)kind; (void)a_cps; (void)a_offs; (void)b_cps; (void)b_offs; (void)n_pairs; (void)out_dist;
-    return fail(FZ_ERR_INVALID, "fz_distance_batch is not implemented by this build");
+    if (kind != 0 && kind != 1) return fail(FZ_ERR_INVALID, "kind must be 0 (InDel) or 1 (Levenshtein)");
+    if (n_pairs == 0) return FZ_OK;
+    if (!a_offs || !b_offs || !out_dist) return fail(FZ_ERR_INVALID, "null argument");
+    std::map<std::u32string, std::vector<uint64_t>> groups;
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        if (a_offs[i + 1] < a_offs[i] || b_offs[i + 1] < b_offs[i]) return fail(FZ_ERR_INVALID, "offsets not monotone at %llu", (unsigned long long)i);
+        groups[std::u32string(reinterpret_cast<const char32_t *>(a_cps) + a_offs[i], (size_t)(a_offs[i + 1] - a_offs[i]))].push_back(i);
+    }
+    for (auto &g : groups) {
+        std::vector<uint32_t> cps; std::vector<uint64_t> offs{0};
+        for (uint64_t i : g.second) {
+            cps.insert(cps.end(), b_cps + b_offs[i], b_cps + b_offs[i + 1]);
+            offs.push_back(cps.size());
+        }
+        if (cps.empty()) cps.push_back(0);
+        fz_corpus *c = nullptr;
+        int rc = corpus_create(cps.data(), offs.data(), g.second.size(), device, 0, VIEW_RAW, &c);
+        if (rc != FZ_OK) return rc;
+        std::vector<uint32_t> q(g.first.begin(), g.first.end());
+        if (q.empty()) q.push_back(0);
+        uint64_t qo[2] = {0, g.first.size()};
+        std::vector<uint16_t> d(g.second.size());
+        rc = fz_distance_all(c, q.data(), qo, 1, kind, d.data());
+        fz_corpus_destroy(c);
+        if (rc != FZ_OK) return rc;
+        for (size_t j = 0; j < g.second.size(); ++j) out_dist[g.second[j]] = d[j];
+    }
+    return FZ_OK;
 }

@@ -84,7 +84,11 @@ __device__ __forceinline__ void fz_clear_bits(uint32_t *row, uint32_t s, uint32_
 // ---------------------------------------------------------------------------------------------
 // general scoring kernel: any pattern width W (32-bit words), any candidate length
 // ---------------------------------------------------------------------------------------------
-template <int W>
+// MODE: FZ_MODE_TOKEN_SET  token_set_ratio score (u8)
+//       FZ_MODE_RATIO      plain InDel ratio of pattern vs text, thefuzz ratio()/token_sort (u8)
+//       FZ_MODE_INDEL      raw InDel distance (u16)
+//       FZ_MODE_LEV        raw uniform-cost Levenshtein distance, Myers/Hyyro Pv/Mv recurrence (u16)
+template <int W, int MODE>
 __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -122,6 +126,10 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 
         // ---- token intersection: which candidate tokens are query tokens ---------------------
         uint32_t sect1 = 0u, nhits = 0u, prev_end = 0u;
+        if (MODE != FZ_MODE_TOKEN_SET) {
+            // plain views carry one slot per candidate: its length
+            if (td.ntok) prev_end = p.tokend[td.toff + lane];
+        } else
         for (uint32_t i = 0; i < td.ntok; ++i) {
             const uint32_t cid = p.tokid[td.toff + i * 64u + lane];
             const uint32_t cend = p.tokend[td.toff + i * 64u + lane];
@@ -143,12 +151,51 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
         }
         const uint32_t clen = prev_end;                       // pad slots carry end = length
 
+        const uint32_t *symp = p.sym + td.coff + lane;
+        if (MODE == FZ_MODE_LEV) {
+            // ---- Myers/Hyyro bit-vector Levenshtein; the W words act as one big integer --------
+            uint32_t Pv[W], Mv[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) { Pv[w] = 0xFFFFFFFFu; Mv[w] = 0u; }
+            uint32_t dist = q.m;
+            const uint32_t lastw = q.m ? (q.m - 1u) >> 5 : 0u, lastb = q.m ? (q.m - 1u) & 31u : 0u;
+            for (uint32_t d = 0; d < td.ndw; ++d) {
+                const uint32_t cw = symp[d * 64u];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (d * 4u + (uint32_t)k < clen && q.m != 0u) {     // padding is not text here
+                        const uint32_t s = (cw >> (8 * k)) & 0xFFu;
+                        const uint32_t *row = s_peq + s * (uint32_t)W;
+                        uint32_t carry = 0u, phc = 1u, mhc = 0u;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) {
+                            const uint32_t Eq = row[w];
+                            const uint32_t Xv = Eq | Mv[w];
+                            const uint64_t t = (uint64_t)(Eq & Pv[w]) + (uint64_t)Pv[w] + (uint64_t)carry;
+                            carry = (uint32_t)(t >> 32);
+                            const uint32_t Xh = ((uint32_t)t ^ Pv[w]) | Eq;
+                            uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+                            uint32_t Mh = Pv[w] & Xh;
+                            if ((uint32_t)w == lastw) dist += ((Ph >> lastb) & 1u) - ((Mh >> lastb) & 1u);
+                            const uint32_t phn = Ph >> 31, mhn = Mh >> 31;
+                            Ph = (Ph << 1) | phc; Mh = (Mh << 1) | mhc;
+                            phc = phn; mhc = mhn;
+                            Pv[w] = Mh | ~(Xv | Ph);
+                            Mv[w] = Ph & Xv;
+                        }
+                    }
+                }
+            }
+            if (q.m == 0u) dist = clen;
+            reinterpret_cast<uint16_t *>(p.scores)[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint16_t)dist;
+            continue;
+        }
+
         uint32_t M[W], V[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) { M[w] = Mrow[w * 64]; V[w] = 0xFFFFFFFFu; }
 
         // ---- bit-parallel LCS over the kept text --------------------------------------------
-        const uint32_t *symp = p.sym + td.coff + lane;
         uint32_t tkw = 0u;
         for (uint32_t d = 0; d < td.ndw; ++d) {
             const uint32_t cw = symp[d * 64u];
@@ -172,6 +219,17 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
         uint32_t lcs1 = 0u;
 #pragma unroll
         for (int w = 0; w < W; ++w) lcs1 += (uint32_t)__builtin_popcount(~V[w]);
+
+        if (MODE == FZ_MODE_RATIO || MODE == FZ_MODE_INDEL) {
+            const uint32_t L = q.m + clen, dist = L - 2u * lcs1;
+            if (MODE == FZ_MODE_INDEL) {
+                reinterpret_cast<uint16_t *>(p.scores)[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint16_t)dist;
+            } else {
+                const uint32_t sc = L ? fz_round_ratio(dist, L, p.ties) : 100u;   // two empty strings: 100
+                p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
+            }
+            continue;
+        }
 
         const uint32_t sc = fz_token_set_score(q.n_tok, q.m, clen, nhits, sect1, lcs1, p.ties);
         p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
@@ -380,34 +438,46 @@ size_t fz_score_lds_bytes(int W, const FzScoreParams &p)
     return 4ull * ((size_t)p.alphabet * W + 3ull * p.pmax + (size_t)p.nwaves * 64ull * ((size_t)W + p.ntkw));
 }
 
-template <int W>
-static hipError_t launch_general(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
+template <int W, int MODE>
+static hipError_t launch_general2(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
 {
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_general<W>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_general<W, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(fz_score_general<W>, grid, dim3(p.nwaves * 64u), lds, st, p);
+    hipLaunchKernelGGL((fz_score_general<W, MODE>), grid, dim3(p.nwaves * 64u), lds, st, p);
     return hipGetLastError();
 }
 
-hipError_t fz_launch_score(int W, const FzScoreParams &p, uint32_t nq, hipStream_t st)
+template <int W>
+static hipError_t launch_general(int mode, const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
+{
+    switch (mode) {
+    case FZ_MODE_TOKEN_SET: return launch_general2<W, FZ_MODE_TOKEN_SET>(p, grid, lds, st);
+    case FZ_MODE_RATIO: return launch_general2<W, FZ_MODE_RATIO>(p, grid, lds, st);
+    case FZ_MODE_INDEL: return launch_general2<W, FZ_MODE_INDEL>(p, grid, lds, st);
+    case FZ_MODE_LEV: return launch_general2<W, FZ_MODE_LEV>(p, grid, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq, hipStream_t st)
 {
     if (nq == 0u || p.ntiles == 0u) return hipSuccess;
     dim3 grid((p.ntiles + p.tiles_per_block - 1u) / p.tiles_per_block, nq);
     size_t lds = fz_score_lds_bytes(W, p);
     switch (W) {
-    case 1: return launch_general<1>(p, grid, lds, st);
-    case 2: return launch_general<2>(p, grid, lds, st);
-    case 3: return launch_general<3>(p, grid, lds, st);
-    case 4: return launch_general<4>(p, grid, lds, st);
-    case 6: return launch_general<6>(p, grid, lds, st);
-    case 8: return launch_general<8>(p, grid, lds, st);
-    case 12: return launch_general<12>(p, grid, lds, st);
-    case 16: return launch_general<16>(p, grid, lds, st);
-    case 24: return launch_general<24>(p, grid, lds, st);
-    case 32: return launch_general<32>(p, grid, lds, st);
+    case 1: return launch_general<1>(mode, p, grid, lds, st);
+    case 2: return launch_general<2>(mode, p, grid, lds, st);
+    case 3: return launch_general<3>(mode, p, grid, lds, st);
+    case 4: return launch_general<4>(mode, p, grid, lds, st);
+    case 6: return launch_general<6>(mode, p, grid, lds, st);
+    case 8: return launch_general<8>(mode, p, grid, lds, st);
+    case 12: return launch_general<12>(mode, p, grid, lds, st);
+    case 16: return launch_general<16>(mode, p, grid, lds, st);
+    case 24: return launch_general<24>(mode, p, grid, lds, st);
+    case 32: return launch_general<32>(mode, p, grid, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
