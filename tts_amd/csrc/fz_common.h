@@ -51,6 +51,7 @@ struct FzScoreParams {
     uint32_t pmax;            // capacity of the per-query token arrays in LDS
     uint32_t ntkw;            // text keep-mask words per lane (ceil(max ndw / 8))
     uint32_t nwaves;          // waves per block
+    const uint32_t *tile_list;// optional: indices of the tiles to cover (null = 0..ntiles-1)
     const FzQuery *queries;   // queries of this launch (blockIdx.y indexes it)
     const uint32_t *qblob;    // Peq tables
     const uint32_t *qtok_id;
@@ -59,6 +60,45 @@ struct FzScoreParams {
     uint8_t *scores;          // [rows][row_stride]
     uint64_t row_stride;
     FzTies ties;
+};
+
+// ---- stream kernel (fz_score_stream): short candidates as per-lane patterns, queries as text -----
+// Eligible tiles: <= 8 token slots and <= 32*W symbols (W = 1, 2).  Eligible queries: see
+// fz_host.cpp build_stream.  The query side is a stream of 16-byte records, the same for every lane:
+//   header  {out_row, m, n_ids, n_tok_recs}
+//   ids     ceil(n_ids / 4) records of 4 vocabulary ids (pad FZ_QTOK_PAD): the query tokens that
+//           exist in the corpus vocabulary, the only ones that can intersect
+//   tokens  n_tok_recs records {id, nsym | last << 8, 4 symbols, 4 symbols}: up to 8 text symbols
+//           of one token, each byte = 4 * (Peq row of the symbol); a longer token continues in the
+//           next record (id = FZ_QTOK_CONT); `last` marks the record that ends the token, after
+//           which the separator step follows (token_set only).  Symbols no candidate uses are
+//           dropped on the host: they cannot change the LCS state.
+#define FZ_STREAM_MAX_TOK 8u      // token slots of an eligible tile
+#define FZ_STREAM_MAX_ROWS 63u    // Peq rows (distinct text symbols of one launch), row byte = 4*row < 256
+#define FZ_STREAM_TAB 128u        // score table is [FZ_STREAM_TAB][FZ_STREAM_TAB]: T[L][d], L, d < 128
+#define FZ_QTOK_UNKNOWN 0xFFFFFFFEu   // token that is not in the corpus vocabulary
+#define FZ_QTOK_CONT 0xFFFFFFFDu      // continuation record of the previous token
+#define FZ_QTOK_PAD 0xFFFFFFFCu       // padding of an id record
+
+struct FzRec { uint32_t x, y, z, w; };
+
+struct FzStreamParams {
+    const uint32_t *sym;
+    const uint32_t *tokid;
+    const uint16_t *tokend;
+    const FzTile *tiles;
+    const uint32_t *tile_list; // indices of the eligible tiles
+    uint32_t ntiles;           // entries of tile_list
+    uint32_t nwaves;           // waves per block = tiles per block
+    uint32_t stride;           // dwords per lane of one Peq table word plane (odd, > max row)
+    uint32_t nq;               // queries of this launch
+    uint32_t q_per_block;
+    const uint8_t *row_of_sym; // [256] corpus symbol -> 4 * row, 0xFF = no query of this launch uses it
+    const FzRec *recs;         // record stream
+    const uint32_t *qrec;      // [nq] index of each query's header record
+    const uint8_t *score_tab;  // [128*128] rounded ratio T[L*128 + d]
+    uint8_t *scores;
+    uint32_t row_stride;       // bytes per score row (< 2^32)
 };
 
 struct FzSelectParams {

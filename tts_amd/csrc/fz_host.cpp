@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -26,6 +27,8 @@ int fz_pick_width(uint32_t m);
 size_t fz_score_lds_bytes(int W, const FzScoreParams &p);
 hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq, hipStream_t st);
 hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st);
+size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves);
+hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -111,6 +114,9 @@ struct View {
     uint32_t *d_sym = nullptr, *d_tokid = nullptr, *d_orig_of_phys = nullptr, *d_phys_of_orig = nullptr;
     uint16_t *d_tokend = nullptr;
     FzTile *d_tiles = nullptr;
+    // tile indices by kernel: stream kernel with 1 / 2 pattern words, general kernel for the rest
+    uint32_t *d_tiles_s1 = nullptr, *d_tiles_s2 = nullptr, *d_tiles_slow = nullptr;
+    uint32_t n_s1 = 0, n_s2 = 0, n_slow = 0;
     std::vector<uint32_t> h_orig_of_phys;
 };
 
@@ -130,6 +136,9 @@ struct fz_corpus {
     uint8_t *d_qbuf = nullptr; size_t qbuf_cap = 0;
     uint64_t *d_keys = nullptr; size_t keys_cap = 0;
     uint32_t *d_cnt = nullptr; size_t cnt_cap = 0;
+    uint8_t *d_score_tab[2] = {nullptr, nullptr};         // stream kernel: T[L][d] per rounding form
+    bool use_stream = true;                               // FUZZYHIP_NO_STREAM=1 forces the general kernel
+    uint32_t stream_waves = 16, stream_blocks = 8192;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
     std::vector<hipEvent_t> events;
     fz_timing timing{};
     std::mutex mu;
@@ -164,6 +173,28 @@ static void make_tie_tables()
     }
 }
 
+// exact integer form of the rounded ratio (the device twin is fz_round_ratio in fz_kernels.hip)
+static uint32_t round_ratio_host(uint32_t d, uint32_t L, const FzTies &t)
+{
+    const uint32_t N = 100u * (L - d);
+    uint32_t q = N / L;
+    const uint32_t twice = 2u * (N % L);
+    if (twice > L) q += 1;
+    else if (twice == L) q += (uint32_t)(((q < 64 ? t.lo >> q : t.hi >> (q - 64))) & 1ull);
+    return q;
+}
+
+// stream kernel score table: T[L * 128 + d] = rounded ratio of distance d at length sum L
+// (d <= L < 128); T[0][0] = 100 is thefuzz's score of two empty strings under ratio().
+static std::vector<uint8_t> make_score_table(const FzTies &t)
+{
+    std::vector<uint8_t> tab((size_t)FZ_STREAM_TAB * FZ_STREAM_TAB, 0);
+    tab[0] = 100;
+    for (uint32_t L = 1; L < FZ_STREAM_TAB; ++L)
+        for (uint32_t d = 0; d <= L; ++d) tab[(size_t)L * FZ_STREAM_TAB + d] = (uint8_t)round_ratio_host(d, L, t);
+    return tab;
+}
+
 template <typename T>
 static int upload(T **dptr, const std::vector<T> &h, uint64_t *bytes)
 {
@@ -190,7 +221,8 @@ extern "C" int fz_device_count(int *out_n)
 static void free_view(View &v)
 {
     for (void *p : {(void *)v.d_sym, (void *)v.d_tokid, (void *)v.d_tokend, (void *)v.d_tiles,
-                    (void *)v.d_orig_of_phys, (void *)v.d_phys_of_orig})
+                    (void *)v.d_orig_of_phys, (void *)v.d_phys_of_orig, (void *)v.d_tiles_s1,
+                    (void *)v.d_tiles_s2, (void *)v.d_tiles_slow})
         if (p) (void)hipFree(p);
     v = View();
 }
@@ -201,7 +233,8 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (View &v : c->views) free_view(v);
-    for (void *p : {(void *)c->d_scores, (void *)c->d_qbuf, (void *)c->d_keys, (void *)c->d_cnt})
+    for (void *p : {(void *)c->d_scores, (void *)c->d_qbuf, (void *)c->d_keys, (void *)c->d_cnt,
+                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1]})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -354,6 +387,16 @@ static int build_view(fz_corpus *c, int kind)
     if ((rc = upload(&v.d_tiles, tiles, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_orig_of_phys, v.h_orig_of_phys, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_phys_of_orig, phys_of_orig, &v.device_bytes)) != FZ_OK) return rc;
+    std::vector<uint32_t> ts1, ts2, tslow;
+    for (uint32_t t = 0; t < v.ntiles; ++t) {
+        if (tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
+        else if (tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
+        else tslow.push_back(t);
+    }
+    v.n_s1 = (uint32_t)ts1.size(); v.n_s2 = (uint32_t)ts2.size(); v.n_slow = (uint32_t)tslow.size();
+    if ((rc = upload(&v.d_tiles_s1, ts1, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload(&v.d_tiles_s2, ts2, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload(&v.d_tiles_slow, tslow, &v.device_bytes)) != FZ_OK) return rc;
     v.built = true;
     return FZ_OK;
 }
@@ -385,6 +428,14 @@ static int corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, 
     for (uint64_t i = 0; i <= n; ++i) c->h_offs[i] = n ? offs[i] - lo : 0;
     int rc = build_view(c, eager_view);
     if (rc != FZ_OK) { fz_corpus_destroy(c); return rc; }
+    for (int form = 0; form < 2 && rc == FZ_OK; ++form) {
+        uint64_t unused = 0;
+        rc = upload(&c->d_score_tab[form], make_score_table(form == 0 ? g_ties_norm_distance : g_ties_norm_sim), &unused);
+    }
+    if (rc != FZ_OK) { fz_corpus_destroy(c); return rc; }
+    if (const char *e = getenv("FUZZYHIP_NO_STREAM")) c->use_stream = !(e[0] == '1');
+    if (const char *e = getenv("FUZZYHIP_STREAM_WAVES")) c->stream_waves = (uint32_t)std::max(1, atoi(e));
+    if (const char *e = getenv("FUZZYHIP_STREAM_BLOCKS")) c->stream_blocks = (uint32_t)std::max(1, atoi(e));
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { fz_corpus_destroy(c); return fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
@@ -437,10 +488,78 @@ extern "C" int fz_last_timing(const fz_corpus *c, fz_timing *out)
 // query preparation
 // ---------------------------------------------------------------------------------------------
 struct QueryBatch {
-    // per width class W: the prepared queries that use fz_score_general<W>
+    // per width class W: the prepared queries that use fz_score_general<W> over every tile ...
     std::map<int, std::vector<FzQuery>> classes;
+    // ... and those the stream kernel covers; the general kernel then only sees the slow tiles
+    std::map<int, std::vector<FzQuery>> slow_classes;
     std::vector<uint32_t> peq, tok_id, tok_pos, tok_len1;
+    // stream kernel input (fz_common.h FzStreamParams)
+    bool allow_stream = false;
+    uint32_t stream_max_m = 0;           // longest pattern the score table covers
+    std::vector<FzRec> recs;
+    std::vector<uint32_t> qrec;
+    uint8_t row_of_sym[256];
+    uint32_t nrows = 0;
+    QueryBatch() { memset(row_of_sym, 0xFF, sizeof row_of_sym); }
 };
+
+// Appends the stream records of one query; false (and nothing appended) when the query is not
+// eligible: too long for the score table, or its symbols would overflow the Peq rows of the launch.
+//   text: the symbols of the query text in order; for VIEW_SET, `tok_first[t]`..`tok_first[t+1]` are
+//   the symbols of token t (code points no candidate uses already dropped) and ids[t] its vocabulary
+//   id or FZ_QTOK_UNKNOWN; for the other views there is one pseudo token.
+static bool stream_append(QueryBatch &b, bool token_set, uint32_t out_row, uint32_t m,
+                          const std::vector<uint8_t> &text, const std::vector<uint32_t> &tok_first,
+                          const std::vector<uint32_t> &ids)
+{
+    if (!b.allow_stream || m > b.stream_max_m) return false;
+    // rows for symbols this launch has not seen yet
+    uint8_t fresh[256]; uint32_t nfresh = 0;
+    for (uint8_t sy : text) {
+        if (b.row_of_sym[sy] != 0xFF) continue;
+        bool dup = false;
+        for (uint32_t i = 0; i < nfresh; ++i) dup |= fresh[i] == sy;
+        if (!dup) fresh[nfresh++] = sy;
+    }
+    if (b.nrows + nfresh > FZ_STREAM_MAX_ROWS + 1u) return false;
+    for (uint32_t i = 0; i < nfresh; ++i) b.row_of_sym[fresh[i]] = (uint8_t)(4u * b.nrows++);
+
+    const size_t hdr = b.recs.size();
+    b.qrec.push_back((uint32_t)hdr);
+    b.recs.push_back(FzRec{out_row, m, 0u, 0u});
+    uint32_t n_ids = 0;
+    if (token_set) {
+        FzRec r{FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD};
+        for (uint32_t id : ids) {
+            if (id == FZ_QTOK_UNKNOWN) continue;
+            (&r.x)[n_ids & 3u] = id;
+            if ((++n_ids & 3u) == 0u) { b.recs.push_back(r); r = FzRec{FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD}; }
+        }
+        if (n_ids & 3u) b.recs.push_back(r);
+    }
+    uint32_t nrec = 0;
+    const size_t ntok = tok_first.size() - 1;
+    for (size_t t = 0; t < ntok; ++t) {
+        const uint32_t a = tok_first[t], e = tok_first[t + 1];
+        uint32_t pos = a;
+        bool first = true;
+        do {                                             // an empty token still owns its separator step
+            const uint32_t n = std::min<uint32_t>(8u, e - pos);
+            FzRec r{first ? ids[t] : FZ_QTOK_CONT, n, 0u, 0u};
+            for (uint32_t k = 0; k < n; ++k)
+                (k < 4 ? r.z : r.w) |= (uint32_t)b.row_of_sym[text[pos + k]] << (8u * (k & 3u));
+            pos += n;
+            if (pos >= e) r.y |= 0x100u;                 // last record of the token
+            if (first) r.y |= 0x200u;
+            if (first && ids[t] != FZ_QTOK_UNKNOWN) r.y |= 0x400u;
+            b.recs.push_back(r);
+            ++nrec;
+            first = false;
+        } while (pos < e);
+    }
+    b.recs[hdr].z = n_ids | (nrec << 16);
+    return true;
+}
 
 // VIEW_SET: pattern = sorted unique tokens, each followed by one separator (m code points); tokens
 // known to the corpus vocabulary are listed as (id, first bit, len+1), ascending id, for the
@@ -454,7 +573,10 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
     std::u32string pat;
     struct Trip { uint32_t id, pos, len1; };
     std::vector<Trip> trips;
+    std::vector<uint8_t> text;                 // stream kernel: text symbols, separators left out
+    std::vector<uint32_t> tok_first{0u}, ids;
     uint32_t ntok = 0;
+    auto sym_of = [&](uint32_t cp) -> uint32_t { return cp < 0x110000u ? v.sym_of_cp[cp] : 0u; };
     if (kind == VIEW_RAW) {
         pat.assign(reinterpret_cast<const char32_t *>(s), (size_t)n);
     } else {
@@ -466,6 +588,10 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
             if (kind == VIEW_SET) {
                 auto it = c->vocab.find(t);
                 if (it != c->vocab.end()) trips.push_back({it->second, (uint32_t)pat.size(), (uint32_t)t.size() + 1u});
+                ids.push_back(it != c->vocab.end() ? it->second : FZ_QTOK_UNKNOWN);
+                for (char32_t ch : t)
+                    if (uint32_t sy = sym_of((uint32_t)ch)) text.push_back((uint8_t)sy);
+                tok_first.push_back((uint32_t)text.size());
             }
             pat.append(t);
             if (kind == VIEW_SET) pat.push_back(U' ');
@@ -473,6 +599,18 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
     }
     const uint64_t m = pat.size();
     if (m > FZ_MAX_PATTERN) return fail(FZ_ERR_TOO_LONG, "query pattern of %llu code points exceeds FZ_MAX_PATTERN (%u)", (unsigned long long)m, FZ_MAX_PATTERN);
+    if (kind != VIEW_SET) {                    // one pseudo token: the whole text, no separator steps
+        for (char32_t ch : pat) {
+            const uint32_t sy = (kind == VIEW_SORT && ch == U' ') ? FZ_SYM_SPACE : sym_of((uint32_t)ch);
+            if (sy) text.push_back((uint8_t)sy);
+        }
+        tok_first.push_back((uint32_t)text.size());
+        ids.push_back(FZ_QTOK_UNKNOWN);
+    }
+    const bool streamed = (kind != VIEW_SET || ntok > 0) &&
+                          stream_append(b, kind == VIEW_SET, out_row, (uint32_t)m, text, tok_first, ids);
+    if (streamed && v.n_slow == 0) return FZ_OK;          // nothing left for the general kernel
+
     const int W = fz_pick_width((uint32_t)m);
     FzQuery q{};
     q.peq_off = (uint32_t)b.peq.size();
@@ -486,13 +624,13 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
         uint32_t cp = (uint32_t)pat[bit];
         uint32_t sym;
         if (kind == VIEW_SET && cp == 0x20u) sym = FZ_SYM_SPACE;       // the separators just added
-        else sym = cp < 0x110000u ? v.sym_of_cp[cp] : 0u;
+        else sym = sym_of(cp);
         if (sym) peq[sym * W + (bit >> 5)] |= 1u << (bit & 31u);
     }
     std::sort(trips.begin(), trips.end(), [](const Trip &a, const Trip &b2) { return a.id < b2.id; });
     q.n_ids = (uint32_t)trips.size();
     for (const Trip &t : trips) { b.tok_id.push_back(t.id); b.tok_pos.push_back(t.pos); b.tok_len1.push_back(t.len1); }
-    b.classes[W].push_back(q);
+    (streamed ? b.slow_classes : b.classes)[W].push_back(q);
     return FZ_OK;
 }
 
@@ -615,30 +753,47 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
         const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, nq - q0);
         auto t0 = std::chrono::steady_clock::now();
         QueryBatch b;
+        const bool stream_mode = kmode == FZ_MODE_TOKEN_SET || kmode == FZ_MODE_RATIO;
+        b.allow_stream = c->use_stream && stream_mode && (v.n_s1 + v.n_s2) > 0 && row_stride <= 0xFFFFFFFFull;
+        // the score table covers L < 128; a stream tile holds at most 64 symbols.  token_set looks up
+        // L = m + clen - 2, ratio L = m + clen.
+        b.stream_max_m = kmode == FZ_MODE_TOKEN_SET ? (FZ_STREAM_TAB + 1u - 64u) : (FZ_STREAM_TAB - 1u - 64u);
         for (uint32_t r = 0; r < rows; ++r) {
             const uint64_t qi = q0 + r;
             if (q_offs[qi + 1] < q_offs[qi]) return fail(FZ_ERR_INVALID, "query offsets not monotone at %llu", (unsigned long long)qi);
             rc = prepare_query(c, view_kind, q_cps + q_offs[qi], q_offs[qi + 1] - q_offs[qi], r, b, toks);
             if (rc != FZ_OK) return rc;
         }
-        // one device blob: [FzQuery list by class][peq][tok_id][tok_pos][tok_len1]
+        b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches two records ahead
+        b.recs.push_back(FzRec{0, 0, 0, 0});
+        // one device blob: [FzQuery list][peq][tok_id][tok_pos][tok_len1][stream records][qrec][rows]
+        struct Launch { int W; uint32_t first, count; bool slow_only; };
         std::vector<FzQuery> qlist;
-        std::vector<std::pair<int, std::pair<uint32_t, uint32_t>>> launches;   // W -> (first, count)
-        for (auto &kv : b.classes) {
-            launches.push_back({kv.first, {(uint32_t)qlist.size(), (uint32_t)kv.second.size()}});
-            qlist.insert(qlist.end(), kv.second.begin(), kv.second.end());
-        }
-        const size_t o_q = 0, o_peq = o_q + qlist.size() * sizeof(FzQuery);
+        std::vector<Launch> launches;
+        for (int pass = 0; pass < 2; ++pass)
+            for (auto &kv : (pass == 0 ? b.classes : b.slow_classes)) {
+                launches.push_back({kv.first, (uint32_t)qlist.size(), (uint32_t)kv.second.size(), pass == 1});
+                qlist.insert(qlist.end(), kv.second.begin(), kv.second.end());
+            }
+        auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        const size_t o_q = 0, o_peq = align16(o_q + qlist.size() * sizeof(FzQuery));
         const size_t o_id = o_peq + b.peq.size() * 4, o_pos = o_id + b.tok_id.size() * 4;
-        const size_t o_len = o_pos + b.tok_pos.size() * 4, total = o_len + b.tok_len1.size() * 4;
-        std::vector<uint8_t> blob(std::max<size_t>(total, 16));
-        memcpy(blob.data() + o_q, qlist.data(), qlist.size() * sizeof(FzQuery));
+        const size_t o_len = o_pos + b.tok_pos.size() * 4;
+        const size_t o_rec = align16(o_len + b.tok_len1.size() * 4);
+        const size_t o_qrec = o_rec + b.recs.size() * sizeof(FzRec);
+        const size_t o_rows = align16(o_qrec + b.qrec.size() * 4);
+        const size_t total = o_rows + 256;
+        std::vector<uint8_t> blob(total);
+        if (!qlist.empty()) memcpy(blob.data() + o_q, qlist.data(), qlist.size() * sizeof(FzQuery));
         if (!b.peq.empty()) memcpy(blob.data() + o_peq, b.peq.data(), b.peq.size() * 4);
         if (!b.tok_id.empty()) {
             memcpy(blob.data() + o_id, b.tok_id.data(), b.tok_id.size() * 4);
             memcpy(blob.data() + o_pos, b.tok_pos.data(), b.tok_pos.size() * 4);
             memcpy(blob.data() + o_len, b.tok_len1.data(), b.tok_len1.size() * 4);
         }
+        memcpy(blob.data() + o_rec, b.recs.data(), b.recs.size() * sizeof(FzRec));
+        if (!b.qrec.empty()) memcpy(blob.data() + o_qrec, b.qrec.data(), b.qrec.size() * 4);
+        memcpy(blob.data() + o_rows, b.row_of_sym, 256);
         c->timing.host_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if ((rc = ensure(&c->d_qbuf, &c->qbuf_cap, blob.size())) != FZ_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->d_qbuf, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
@@ -648,11 +803,13 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
         if (!e0 || !e1) return fail(FZ_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(e0, st));
         for (auto &l : launches) {
-            const int W = l.first;
-            const uint32_t first = l.second.first, count = l.second.second;
+            const int W = l.W;
+            const uint32_t first = l.first, count = l.count;
             FzScoreParams p{};
             p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
-            p.ntiles = v.ntiles; p.alphabet = v.alphabet;
+            p.ntiles = l.slow_only ? v.n_slow : v.ntiles;
+            p.tile_list = l.slow_only ? v.d_tiles_slow : nullptr;
+            p.alphabet = v.alphabet;
             uint32_t pmax = 1;
             for (uint32_t i = 0; i < count; ++i) pmax = std::max(pmax, qlist[first + i].n_ids);
             p.pmax = pmax;
@@ -661,7 +818,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             while (p.nwaves > 1 && fz_score_lds_bytes(W, p) > 64 * 1024) p.nwaves >>= 1;
             if (fz_score_lds_bytes(W, p) > 160 * 1024)
                 return fail(FZ_ERR_TOO_LONG, "pattern width %d words x candidate length %u does not fit in LDS", W, v.max_len);
-            uint64_t work = (uint64_t)v.ntiles * count;
+            uint64_t work = (uint64_t)p.ntiles * count;
             uint32_t tpb = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(p.nwaves, work / 8192));
             tpb = (tpb + p.nwaves - 1) / p.nwaves * p.nwaves;
             p.tiles_per_block = tpb;
@@ -674,6 +831,32 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             p.ties = ties;
             HIP_TRY(fz_launch_score(W, kmode, p, count, st));
             c->timing.score_launches++;
+        }
+        if (!b.qrec.empty()) {
+            const uint32_t stride = b.nrows <= 41u ? 41u : 65u;
+            for (int W = 1; W <= 2; ++W) {
+                const uint32_t nt = W == 1 ? v.n_s1 : v.n_s2;
+                if (nt == 0) continue;
+                FzStreamParams p{};
+                p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
+                p.tile_list = W == 1 ? v.d_tiles_s1 : v.d_tiles_s2;
+                p.ntiles = nt; p.stride = stride;
+                p.nwaves = 16;
+                while (p.nwaves > 1 && fz_stream_lds_bytes(W, (int)stride, p.nwaves) > 160 * 1024) --p.nwaves;
+                p.nwaves = std::min<uint32_t>(p.nwaves, std::max<uint32_t>(1, c->stream_waves));
+                p.nq = (uint32_t)b.qrec.size();
+                // enough blocks to balance the chip, enough queries per block to amortise the tile set-up
+                const uint64_t bx = (nt + p.nwaves - 1) / p.nwaves;
+                uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (c->stream_blocks + bx - 1) / bx));
+                p.q_per_block = (uint32_t)((p.nq + by - 1) / by);
+                p.row_of_sym = c->d_qbuf + o_rows;
+                p.recs = reinterpret_cast<const FzRec *>(c->d_qbuf + o_rec);
+                p.qrec = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_qrec);
+                p.score_tab = c->d_score_tab[kmode == FZ_MODE_TOKEN_SET ? 0 : 1];
+                p.scores = c->d_scores; p.row_stride = (uint32_t)row_stride;
+                HIP_TRY(fz_launch_stream(W, kmode, p, st));
+                c->timing.score_launches++;
+            }
         }
         HIP_TRY(hipEventRecord(e1, st));
         score_spans.push_back({ev - 2, ev - 1});

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 
     uint32_t t_end = (blockIdx.x + 1u) * p.tiles_per_block;
     if (t_end > p.ntiles) t_end = p.ntiles;
-    for (uint32_t tile = blockIdx.x * p.tiles_per_block + wave; tile < t_end; tile += p.nwaves) {
+    for (uint32_t tix = blockIdx.x * p.tiles_per_block + wave; tix < t_end; tix += p.nwaves) {
+        const uint32_t tile = p.tile_list ? p.tile_list[tix] : tix;
         const FzTile td = p.tiles[tile];
         const uint32_t ntkw = ((uint32_t)td.ndw + 7u) >> 3;
 
@@ -234,6 +235,273 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
         const uint32_t sc = fz_token_set_score(q.n_tok, q.m, clen, nhits, sect1, lcs1, p.ties);
         p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// stream scoring kernel: short candidates as per-lane PATTERNS, queries streamed as wave-uniform TEXT
+// ---------------------------------------------------------------------------------------------
+// LCS is symmetric, so the roles of the general kernel are swapped here: one wave owns one tile, every
+// lane keeps ITS candidate's match masks (Peq, one row per text symbol that any query of the launch
+// uses) in a private LDS column, and the queries of the block pass by as a stream of 16-byte records
+// that is the same for all lanes (FzStreamParams, fz_common.h).  Per text symbol that costs one
+// conflict-free ds_read_b32 at (lane column + row) and the three-instruction Hyyro update; the
+// candidate side is built once per tile and reused for every query of the block.
+//   token intersection: brute-force id compares, candidate ids in VGPRs against the record's ids;
+//     a candidate token that the query also has is cleared from the pattern keep-mask M, a query
+//     token that the candidate also has is scanned with an all-zero mask (it can match nothing).
+//   separator: every token of either side is followed by one separator; its
+//     match mask lives in a register, so the step after a token needs no lookup.
+//   score: T[L][d] = the rounded ratio, a 16 KiB table the host fills with the scorer's own
+//     rounding (fz_host.cpp make_score_table); both ratios of token_set_ratio are lookups.
+// The table is indexed [lane][row] with an odd stride: lanes hit distinct banks for any row.
+template <int W, int STRIDE>
+__device__ __forceinline__ void fz_stream_step(uint32_t (&V)[W], const uint32_t (&row)[W], const uint32_t (&Mk)[W])
+{
+    if (W == 1) {
+        const uint32_t v = V[0];
+        const uint32_t u = __builtin_amdgcn_bitop3_b32(v, row[0], Mk[0], 0x80);        // v & row & Mk
+        V[0] = __builtin_amdgcn_bitop3_b32(v + u, v, u, 0xF6);                         // (v + u) | (v ^ u)
+    } else {
+        const uint32_t v0 = V[0], v1 = V[W - 1];
+        const uint32_t u0 = __builtin_amdgcn_bitop3_b32(v0, row[0], Mk[0], 0x80);
+        const uint32_t u1 = __builtin_amdgcn_bitop3_b32(v1, row[W - 1], Mk[W - 1], 0x80);
+        const uint64_t a = (((uint64_t)v1 << 32) | v0) + (((uint64_t)u1 << 32) | u0);
+        V[0] = __builtin_amdgcn_bitop3_b32((uint32_t)a, v0, u0, 0xF6);
+        V[W - 1] = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), v1, u1, 0xF6);
+    }
+}
+
+// the query loop of one tile, specialised on the tile's token slots NT (the id compares are unrolled
+// over exactly NT candidate tokens; padding slots hold FZ_TOK_NONE, which no record id equals)
+template <int W, int MODE, int STRIDE, int NT>
+__device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const FzRec *__restrict__ recs,
+                                                  uint8_t *__restrict__ scores, const uint8_t *s_tab,
+                                                  const uint8_t *col, const uint32_t (&cid)[FZ_STREAM_MAX_TOK],
+                                                  const uint32_t (&Rm)[FZ_STREAM_MAX_TOK][W],
+                                                  const uint32_t (&psep)[W], uint32_t clen, uint32_t out_off)
+{
+    constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;
+    uint32_t q0 = blockIdx.y * p.q_per_block, q1 = q0 + p.q_per_block;
+    if (q1 > p.nq) q1 = p.nq;
+    uint32_t ri = p.qrec[q0];
+    FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with two padding records
+#define FZ_ADVANCE() do { cur = nxt; nxt = recs[ri + 2u]; ++ri; } while (0)
+
+    for (uint32_t q = q0; q < q1; ++q) {
+        // header {out_row, m, n_ids | n_tok_recs << 16, -}
+        const uint32_t out_row = cur.x, m = cur.y;
+        const uint32_t n_ids = cur.z & 0xFFFFu, nrec = cur.z >> 16;
+        FZ_ADVANCE();
+
+        uint32_t M[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) M[w] = 0xFFFFFFFFu;
+        if (MODE == FZ_MODE_TOKEN_SET) {
+            bool hit[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) hit[i] = false;
+            for (uint32_t j = 0; j < n_ids; j += 4u) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    hit[i] |= (cid[i] == cur.x) | (cid[i] == cur.y) | (cid[i] == cur.z) | (cid[i] == cur.w);
+                FZ_ADVANCE();
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int w = 0; w < W; ++w) M[w] &= hit[i] ? ~Rm[i][w] : 0xFFFFFFFFu;
+        }
+
+        uint32_t V[W], Mk[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { V[w] = 0xFFFFFFFFu; Mk[w] = M[w]; }
+        for (uint32_t r = 0; r < nrec; ++r) {
+            // token record {id, nsym | last << 8 | first << 9 | known << 10, symbols 0-3, symbols 4-7}
+            const uint32_t id = cur.x, meta = cur.y, s03 = cur.z, s47 = cur.w;
+            const uint32_t nsym = meta & 0xFFu;
+            uint32_t row[8][W];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t b = ((k < 4 ? s03 : s47) >> (8 * (k & 3))) & 0xFFu;
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    row[k][w] = *reinterpret_cast<const uint32_t *>(col + (uint32_t)w * PLANE + b);
+            }
+            if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x200u)) {
+                bool skip = false;
+                if (meta & 0x400u) {
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) skip |= cid[i] == id;
+                }
+#pragma unroll
+                for (int w = 0; w < W; ++w) Mk[w] = skip ? 0u : M[w];
+            }
+            // all eight rows are in flight before the first guarded step: the empty asm pins them
+            // here, and its memory clobber keeps the next record's scalar load BELOW the wait so that
+            // the load overlaps this record's steps instead of being waited for at once
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int w = 0; w < W; ++w) asm volatile("" : "+v"(row[k][w]) : : "memory");
+            FZ_ADVANCE();
+            if (nsym > 0u) { fz_stream_step<W, STRIDE>(V, row[0], Mk);
+            if (nsym > 1u) { fz_stream_step<W, STRIDE>(V, row[1], Mk);
+            if (nsym > 2u) { fz_stream_step<W, STRIDE>(V, row[2], Mk);
+            if (nsym > 3u) { fz_stream_step<W, STRIDE>(V, row[3], Mk);
+            if (nsym > 4u) { fz_stream_step<W, STRIDE>(V, row[4], Mk);
+            if (nsym > 5u) { fz_stream_step<W, STRIDE>(V, row[5], Mk);
+            if (nsym > 6u) { fz_stream_step<W, STRIDE>(V, row[6], Mk);
+            if (nsym > 7u) { fz_stream_step<W, STRIDE>(V, row[7], Mk); } } } } } } } }
+            if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x100u)) fz_stream_step<W, STRIDE>(V, psep, Mk);
+        }
+
+        uint32_t lcs = 0u;
+#pragma unroll
+        for (int w = 0; w < W; ++w) lcs += (uint32_t)__builtin_popcount(~V[w]);
+        uint32_t sc;
+        if (MODE == FZ_MODE_TOKEN_SET) {
+            // with sect1 = sum(len+1) over the common tokens, PA = m - sect1, TB = clen - sect1:
+            //   r0 = T[m + clen - 2][PA + TB - 2*lcs]              (the joined differences)
+            //   r1 = T[2*sect1 - 2 + min(PA, TB)][min(PA, TB)]     (intersection vs intersection + shorter
+            //        difference; 100 when one side is contained in the other), used when sect1 > 0
+            uint32_t sect1 = 0u;
+#pragma unroll
+            for (int w = 0; w < W; ++w) sect1 += (uint32_t)__builtin_popcount(~M[w]);
+            const uint32_t mc = m + clen;
+            const uint32_t d0 = mc - 2u * (sect1 + lcs);
+            const uint32_t r0 = s_tab[(((mc - 2u) << 7) + d0) & 0x3FFFu];
+            const uint32_t d1 = (m < clen ? m : clen) - sect1;
+            const uint32_t r1 = s_tab[(((2u * sect1 - 2u + d1) << 7) + d1) & 0x3FFFu];
+            sc = (sect1 != 0u && r1 > r0) ? r1 : r0;
+            if (clen == 0u) sc = 0u;                                  // a candidate without tokens scores 0
+        } else {
+            const uint32_t L = m + clen;
+            sc = s_tab[((L << 7) + (L - 2u * lcs)) & 0x3FFFu];        // T[0][0] = 100: two empty strings
+        }
+        uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
+        rowp[out_off] = (uint8_t)sc;
+    }
+#undef FZ_ADVANCE
+}
+
+template <int W, int MODE, int STRIDE>
+__global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const FzRec *__restrict__ recs,
+                                                        uint8_t *__restrict__ scores)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint8_t *s_tab = reinterpret_cast<uint8_t *>(lds);                   // [128][128] rounded ratios
+    uint8_t *s_row = s_tab + FZ_STREAM_TAB * FZ_STREAM_TAB;              // [256] symbol -> 4 * row
+    uint8_t *s_peq = s_row + 256u;                                       // [nwaves][W][64][STRIDE] u32
+    constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;              // bytes of one word plane
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    for (uint32_t i = tid; i < FZ_STREAM_TAB * FZ_STREAM_TAB / 16u; i += blockDim.x)
+        reinterpret_cast<uint4 *>(s_tab)[i] = reinterpret_cast<const uint4 *>(p.score_tab)[i];
+    if (tid < 64u) reinterpret_cast<uint32_t *>(s_row)[tid] = reinterpret_cast<const uint32_t *>(p.row_of_sym)[tid];
+    __syncthreads();                                                     // the only block-wide barrier
+
+    const uint32_t tix = blockIdx.x * p.nwaves + wave;
+    if (tix >= p.ntiles) return;
+    const uint32_t tile = p.tile_list[tix];
+    const FzTile td = p.tiles[tile];
+    const uint32_t ndw = td.ndw, ntok = td.ntok;
+    uint8_t *col = s_peq + wave * ((uint32_t)W * PLANE) + lane * ((uint32_t)STRIDE * 4u);   // this lane's column
+
+    // ---- candidate side, once per tile ----------------------------------------------------------
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+        for (uint32_t r = 0; r < (uint32_t)STRIDE; ++r) *reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r * 4u) = 0u;
+
+    uint32_t cid[FZ_STREAM_MAX_TOK], Rm[FZ_STREAM_MAX_TOK][W], prev_end = 0u;
+#pragma unroll
+    for (int i = 0; i < (int)FZ_STREAM_MAX_TOK; ++i) {
+        uint32_t end = prev_end;
+        cid[i] = FZ_TOK_NONE;
+        if ((uint32_t)i < ntok) {
+            if (MODE == FZ_MODE_TOKEN_SET) cid[i] = p.tokid[td.toff + (uint32_t)i * 64u + lane];
+            end = p.tokend[td.toff + (uint32_t)i * 64u + lane];
+        }
+        const uint64_t hi = end >= 64u ? ~0ull : ((1ull << end) - 1ull);
+        const uint64_t lo = prev_end >= 64u ? ~0ull : ((1ull << prev_end) - 1ull);
+        const uint64_t r = hi & ~lo;                                     // pattern positions of token i
+        Rm[i][0] = (uint32_t)r;
+        if (W == 2) Rm[i][W - 1] = (uint32_t)(r >> 32);
+        prev_end = end;
+    }
+    const uint32_t clen = prev_end;
+
+    uint32_t psep[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) psep[w] = 0u;
+#pragma unroll
+    for (int d = 0; d < 8 * W; ++d) {
+        if ((uint32_t)d < ndw) {
+            const uint32_t cw = p.sym[td.coff + (uint32_t)d * 64u + lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t s = (cw >> (8 * k)) & 0xFFu;
+                const uint32_t bit = 1u << ((d * 4 + k) & 31);
+                const int w = (d * 4 + k) >> 5;
+                if (MODE == FZ_MODE_TOKEN_SET && s == FZ_SYM_SPACE) {
+                    psep[w] |= bit;
+                } else {
+                    const uint32_t r4 = s_row[s];                        // 0xFF: no query uses this symbol
+                    if (r4 != 0xFFu)
+                        __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r4), bit,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+
+    // ---- the queries of this block: a stream of wave-uniform records (scalar loads) ----------------
+    const uint32_t out_off = tile * 64u + lane;
+    if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
+    else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
+    else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
+    else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
+    else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
+    else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
+}
+
+size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves)
+{
+    return (size_t)FZ_STREAM_TAB * FZ_STREAM_TAB + 256u + (size_t)nwaves * W * 64u * stride * 4u;
+}
+
+template <int W, int MODE, int STRIDE>
+static hipError_t launch_stream3(const FzStreamParams &p, hipStream_t st)
+{
+    const size_t lds = fz_stream_lds_bytes(W, STRIDE, p.nwaves);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_stream<W, MODE, STRIDE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((p.ntiles + p.nwaves - 1u) / p.nwaves, (p.nq + p.q_per_block - 1u) / p.q_per_block);
+    hipLaunchKernelGGL((fz_score_stream<W, MODE, STRIDE>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
+    return hipGetLastError();
+}
+
+template <int W, int MODE>
+static hipError_t launch_stream2(const FzStreamParams &p, hipStream_t st)
+{
+    if (p.stride == 41u) return launch_stream3<W, MODE, 41>(p, st);
+    if (p.stride == 65u) return launch_stream3<W, MODE, 65>(p, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_t st)
+{
+    if (p.nq == 0u || p.ntiles == 0u) return hipSuccess;
+    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u) return hipErrorInvalidValue;
+    if (W == 1 && mode == FZ_MODE_TOKEN_SET) return launch_stream2<1, FZ_MODE_TOKEN_SET>(p, st);
+    if (W == 2 && mode == FZ_MODE_TOKEN_SET) return launch_stream2<2, FZ_MODE_TOKEN_SET>(p, st);
+    if (W == 1 && mode == FZ_MODE_RATIO) return launch_stream2<1, FZ_MODE_RATIO>(p, st);
+    if (W == 2 && mode == FZ_MODE_RATIO) return launch_stream2<2, FZ_MODE_RATIO>(p, st);
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------
