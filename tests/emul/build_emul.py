@@ -1,0 +1,49 @@
+"""Builds tests/emul/_build/emul_runner: the UNMODIFIED tts_amd/csrc sources compiled for the CPU
+with g++ -fsanitize=address,undefined over the HIP stand-in of hip_emul.h.  TEST INFRASTRUCTURE
+ONLY (GPU AddressSanitizer is not available on the MI355X pool); the product never loads it.
+
+The only textual changes made to the kernel source on its way to g++ are the two constructs that
+have no host spelling: the dynamic-LDS declaration and the "v" (VGPR) inline-asm constraint."""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "tts_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+BIN = os.path.join(OUT, "emul_runner")
+
+_DYN_LDS = re.compile(r"extern\s+__shared__\s+(?:__align__\(\d+\)\s+)?(\w+)\s+(\w+)\[\];")
+
+
+def _translate(src: str) -> str:
+    src = _DYN_LDS.sub(r"\1 *\2 = reinterpret_cast<\1 *>(emul::dyn_lds());", src)
+    return src.replace('"+v"', '"+r"')
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, f) for f in ("fz_kernels.hip", "fz_host.cpp", "fz_common.h")]
+    srcs += [os.path.join(HERE, f) for f in ("hip_emul.h", "hip_emul.cpp", "emul_runner.cpp", "build_emul.py")]
+    srcs.append(os.path.join(ROOT, "include", "fuzzyhip.h"))
+    if not force and os.path.exists(BIN) and all(os.path.getmtime(BIN) >= os.path.getmtime(s) for s in srcs):
+        return BIN
+    os.makedirs(OUT, exist_ok=True)
+    gen = os.path.join(OUT, "fz_kernels_emul.cpp")
+    with open(os.path.join(CSRC, "fz_kernels.hip")) as f:
+        text = _translate(f.read())
+    with open(gen, "w") as f:
+        f.write(text)
+    flags = ["-std=c++20", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+             "-ffp-contract=off", "-DFZ_EXACT_ALLOC", "-Wno-unknown-pragmas", "-Wno-attributes",
+             "-I" + HERE, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-pthread"]
+    subprocess.check_call(["g++", *flags, gen, os.path.join(CSRC, "fz_host.cpp"),
+                           os.path.join(HERE, "hip_emul.cpp"), os.path.join(HERE, "emul_runner.cpp"),
+                           "-o", BIN])
+    return BIN
+
+
+if __name__ == "__main__":
+    print(build(force=True))

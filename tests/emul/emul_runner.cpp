@@ -1,0 +1,59 @@
+// emul_runner.cpp -- TEST INFRASTRUCTURE ONLY.  Drives the C ABI of include/fuzzyhip.h in the
+// sanitizer (CPU-emulated) build of tts_amd/csrc on one case file and writes the raw results.
+//   case file: 9 x u64 {magic, op, scorer_or_kind, min_score, k, n, ncps, nq, nqcps},
+//              u32 cps[ncps], u64 offs[n+1], u32 qcps[nqcps], u64 qoffs[nq+1]
+//   op 0 fz_score_all -> u8[nq*n];  op 1 fz_distance_all -> u16[nq*n];
+//   op 2 fz_query_topk -> u64 idx[nq*k], i32 score[nq*k], u32 cnt[nq]
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "fuzzyhip.h"
+
+template <typename T>
+static bool rd(FILE *f, std::vector<T> &v, size_t n)
+{
+    v.assign(n ? n : 1, T());
+    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) { fprintf(stderr, "usage: emul_runner case.bin out.bin\n"); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror("case"); return 2; }
+    uint64_t h[9];
+    if (fread(h, 8, 9, f) != 9 || h[0] != 0x465A454D554C0001ull) { fprintf(stderr, "bad case header\n"); return 2; }
+    const uint64_t op = h[1], sk = h[2], k = h[4], n = h[5], ncps = h[6], nq = h[7], nqcps = h[8];
+    const int32_t min_score = (int32_t)(int64_t)h[3];
+    std::vector<uint32_t> cps, qcps; std::vector<uint64_t> offs, qoffs;
+    if (!rd(f, cps, ncps) || !rd(f, offs, n + 1) || !rd(f, qcps, nqcps) || !rd(f, qoffs, nq + 1)) { fprintf(stderr, "short case file\n"); return 2; }
+    fclose(f);
+
+    fz_corpus *c = nullptr;
+    int rc = fz_corpus_create(cps.data(), offs.data(), n, 0, 0, &c);
+    if (rc != FZ_OK) { fprintf(stderr, "fz_corpus_create: %d %s\n", rc, fz_last_error()); return 3; }
+    FILE *o = fopen(argv[2], "wb");
+    if (!o) { perror("out"); return 2; }
+    if (op == 0) {
+        std::vector<uint8_t> out(nq * n ? nq * n : 1);
+        rc = fz_score_all(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, out.data());
+        if (rc == FZ_OK) fwrite(out.data(), 1, nq * n, o);
+    } else if (op == 1) {
+        std::vector<uint16_t> out(nq * n ? nq * n : 1);
+        rc = fz_distance_all(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, out.data());
+        if (rc == FZ_OK) fwrite(out.data(), 2, nq * n, o);
+    } else {
+        std::vector<uint64_t> idx(nq * k ? nq * k : 1);
+        std::vector<int32_t> sc(nq * k ? nq * k : 1);
+        std::vector<uint32_t> cnt(nq ? nq : 1);
+        rc = fz_query_topk(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, min_score, (uint32_t)k, idx.data(), sc.data(), cnt.data());
+        if (rc == FZ_OK) { fwrite(idx.data(), 8, nq * k, o); fwrite(sc.data(), 4, nq * k, o); fwrite(cnt.data(), 4, nq, o); }
+    }
+    fclose(o);
+    if (rc != FZ_OK) { fprintf(stderr, "scoring call: %d %s\n", rc, fz_last_error()); fz_corpus_destroy(c); return 3; }
+    fz_corpus_destroy(c);
+    return 0;
+}

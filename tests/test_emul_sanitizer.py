@@ -1,0 +1,127 @@
+"""Kernel + host sources of libfuzzyhip under AddressSanitizer/UBSan on the CPU.
+
+GPU AddressSanitizer is not available on the MI355X pool, and a kernel that faults there takes the
+whole box down.  tests/emul compiles the UNMODIFIED tts_amd/csrc sources with g++ over a small HIP
+stand-in (one OS thread per work-item) and this file runs tiny cases of every kernel through the C
+ABI under the sanitizers, checking the results against the oracle as well.  This is a checker of
+the sources, not a product path: tts_amd never loads the emulated build."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emul"))
+
+from tts_amd import synth  # noqa: E402
+from tts_amd.preprocess import pack_prepared  # noqa: E402
+
+MAGIC = 0x465A454D554C0001
+
+
+@pytest.fixture(scope="module")
+def runner():
+    import build_emul
+    return build_emul.build()
+
+
+def _run(runner, tmp_path, op, sk, cand, queries, min_score=0, k=0, env=None):
+    cps, offs = pack_prepared(list(cand)) if not isinstance(cand, tuple) else cand
+    qcps, qoffs = pack_prepared(list(queries))
+    n, nq = len(offs) - 1, len(qoffs) - 1
+    ncps, nqcps = int(offs[-1]), int(qoffs[-1])
+    case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
+    with open(case, "wb") as f:
+        np.array([MAGIC, op, sk, np.int64(min_score).astype(np.uint64), k, n, ncps, nq, nqcps], dtype=np.uint64).tofile(f)
+        np.ascontiguousarray(cps[:ncps], dtype=np.uint32).tofile(f)
+        np.ascontiguousarray(offs, dtype=np.uint64).tofile(f)
+        np.ascontiguousarray(qcps[:nqcps], dtype=np.uint32).tofile(f)
+        np.ascontiguousarray(qoffs, dtype=np.uint64).tofile(f)
+    e = dict(os.environ)
+    e["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=0"
+    e["UBSAN_OPTIONS"] = "print_stacktrace=1"
+    e.update(env or {})
+    r = subprocess.run([runner, case, out], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+    raw = np.fromfile(out, dtype=np.uint8)
+    if op == 0:
+        return raw.reshape(nq, n)
+    if op == 1:
+        return raw.view(np.uint16).reshape(nq, n)
+    idx = raw[:nq * k * 8].view(np.uint64).reshape(nq, k)
+    score = raw[nq * k * 8:nq * k * 12].view(np.int32).reshape(nq, k)
+    cnt = raw[nq * k * 12:].view(np.uint32)
+    return idx, score, cnt
+
+
+def _oracle_scores(oracle, scorer, queries, cand):
+    buf, offs = oracle.pack(cand)
+    return np.stack([oracle.score_all(scorer, q, buf, offs) for q in queries]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("no_stream", ["0", "1"])
+def test_token_set_scores_short(oracle, runner, tmp_path, no_stream):
+    cps, offs = synth.make_corpus(330, max_chars=64, seed=11, vocab_size=60)
+    cand = synth.to_strings(cps, offs) + ["", "a", "x" * 64, "ab " * 21 + "c"]
+    queries = synth.make_queries(cps, offs, 9, seed=12) + ["", cand[5], "zz top", "y" * 70]
+    got = _run(runner, tmp_path, 0, 0, cand, queries, env={"FUZZYHIP_NO_STREAM": no_stream})
+    exp = _oracle_scores(oracle, oracle.TOKEN_SET, queries, cand)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]]
+
+
+def test_token_set_multiword(oracle, runner, tmp_path):
+    cps, offs = synth.make_corpus(150, max_chars=300, seed=13, min_tokens=6, max_tokens=40, vocab_size=80)
+    cand = synth.to_strings(cps, offs)
+    queries = [cand[3], cand[77], " ".join(cand[9].split()[:7]), "zz"] + synth.make_queries(cps, offs, 3, seed=14, max_chars=300)
+    got = _run(runner, tmp_path, 0, 0, cand, queries)
+    exp = _oracle_scores(oracle, oracle.TOKEN_SET, queries, cand)
+    assert (got == exp).all()
+
+
+def test_ratio_and_token_sort(oracle, runner, tmp_path):
+    cps, offs = synth.make_corpus(200, max_chars=64, seed=15, vocab_size=40)
+    cand = synth.to_strings(cps, offs) + ["", "q" * 90]
+    queries = synth.make_queries(cps, offs, 5, seed=16) + ["", cand[2], "w" * 80]
+    for sk, orc in ((1, oracle.RATIO), (2, oracle.TOKEN_SORT)):
+        got = _run(runner, tmp_path, 0, sk, cand, queries)
+        exp = _oracle_scores(oracle, orc, queries, cand)
+        assert (got == exp).all(), sk
+
+
+def test_distances(oracle, runner, tmp_path):
+    import random
+    rnd = random.Random(17)
+    cand = ["", "a", "ab"] + ["".join(rnd.choice("abcd ") for _ in range(rnd.randint(0, 140))) for _ in range(90)]
+    queries = ["", "abc"] + ["".join(rnd.choice("abcd ") for _ in range(n)) for n in (31, 32, 33, 64, 65, 130)]
+    for kind, fn in ((0, oracle.indel), (1, oracle.levenshtein)):
+        got = _run(runner, tmp_path, 1, kind, cand, queries)
+        for qi, q in enumerate(queries):
+            for i, s in enumerate(cand):
+                assert int(got[qi, i]) == fn(q, s), (kind, q, s)
+
+
+def test_topk_under_ties(oracle, runner, tmp_path):
+    cps, offs = synth.make_corpus(700, max_chars=32, seed=18, vocab_size=9)
+    cand = synth.to_strings(cps, offs)
+    queries = synth.make_queries(cps, offs, 5, seed=19, max_chars=32) + [cand[0].split()[0], ""]
+    buf, o = oracle.pack(cand)
+    for k, ms in ((10, 35), (1, 0), (5, 100), (300, 50)):
+        idx, score, cnt = _run(runner, tmp_path, 2, 0, cand, queries, min_score=ms, k=k)
+        for qi, q in enumerate(queries):
+            exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, ms, k)
+            got = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
+            assert got == exp, (k, ms, q, got[:5], exp[:5])
+
+
+def test_topk_many_ties_walk(oracle, runner, tmp_path):
+    # > SEL_TIECAP equal scores at the cut: the original-order walk of fz_select_topk
+    cand = ["aa bb"] * 2500 + ["aa"] * 3 + ["cc"] * 20
+    idx, score, cnt = _run(runner, tmp_path, 2, 0, cand, ["aa bb", "cc dd"], min_score=35, k=12)
+    buf, o = oracle.pack(cand)
+    for qi, q in enumerate(["aa bb", "cc dd"]):
+        exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, 35, 12)
+        assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == exp

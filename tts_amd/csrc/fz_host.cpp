@@ -639,7 +639,11 @@ static int ensure(T **p, size_t *cap, size_t need_bytes)
 {
     if (need_bytes <= *cap) return FZ_OK;
     if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+#ifdef FZ_EXACT_ALLOC          // sanitizer build (tests/emul): no slack, so every overrun is seen
+    size_t sz = need_bytes;
+#else
     size_t sz = need_bytes + need_bytes / 4 + 256;
+#endif
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), sz));
     *cap = sz;
     return FZ_OK;

@@ -593,8 +593,8 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
             for (int a = 0; a < 4; ++a) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;
-                    if (s >= tlow && base + (uint32_t)(4 * a + b) < n) atomicAdd(&s_hist[s & 127u], 1u);
+                    const uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;       // a byte > 100 is not a score: skipped
+                    if (s >= tlow && s <= 100u && base + (uint32_t)(4 * a + b) < n) atomicAdd(&s_hist[s], 1u);
                 }
             }
         }
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;
                     const uint32_t ph = base + (uint32_t)(4 * a + b);
-                    if (ph < n && s >= sstar) {
+                    if (ph < n && s >= sstar && s <= 100u) {
                         if (s > sstar) {
                             uint32_t pos = atomicAdd(&s_misc[2], 1u);
                             s_keys[pos] = fz_local_key(s, p.orig_of_phys[ph]);
