@@ -29,6 +29,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def measured_traffic(nq, n, max_chars, k):
+    """HBM bytes per step of the scoring kernels from the committed PMC passes (rocprofv3 FETCH_SIZE /
+    WRITE_SIZE, profiles/r01_traffic.json); None when this run's workload is not the profiled one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None, None
+    w = t.get("workload", {})
+    if (w.get("queries"), w.get("candidates_per_gpu"), w.get("max_chars"), w.get("k")) != (nq, n, max_chars, k):
+        return None, None
+    return t.get("score_kernels_bytes_per_step"), t
+
+
 def cpu_baseline(cps, offs, queries, min_score, k, budget_s=12.0):
     """The oracle's restatement of the reference loop ("port"), 1 host thread, on a bounded sample
     of the same workload.  A reported baseline, not the target."""
@@ -147,6 +161,7 @@ def main():
         bytes_per_query = synth.algorithmic_bytes_per_query(info)
         alg_bytes = float(bytes_per_query) * nq * args.steps
         achieved = alg_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+        traffic, prof = measured_traffic(nq, n, args.max_chars, k)
         out = {
             "metric": "query x candidate pairs/sec (token_set_ratio scoring + threshold + top-k)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -158,7 +173,10 @@ def main():
                        "queries": nq, "candidates_per_gpu": n, "k": k, "min_score": min_score,
                        "parallelism": f"shard{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per step)" if traffic else None,
+                         "valu_busy_frac": prof.get("valu_busy_frac_stream1") if prof else None,
+                         "co_limit": "integer VALU + SALU issue (corpus is Infinity-Cache resident; frac > 1 means cached re-reads, not HBM)",
                          "kernel": "fz_score_*", "launches_per_step": launches / max(args.steps, 1),
                          "algorithmic_bytes_per_step": alg_bytes / args.steps,
                          "kernel_ms_per_step": score_ms / args.steps},
