@@ -333,14 +333,12 @@ double orc_token_set_ratio(const cp_t *a, int64_t na, const cp_t *b, int64_t nb)
 /* rapidfuzz.fuzz.partial_ratio (reference call site app.py:1023), restated by its definition:
  * with s the shorter and l the longer string, the best ratio(s, w) over the windows w of l that
  * rapidfuzz considers: every full window l[i:i+|s|], every prefix l[:i] (i<|s|) and every suffix
- * l[i:] (i > |l|-|s|).  Equal lengths: both directions are tried (the value is symmetric here since
- * the window set is the same).  Empty s: 100 if both empty else 0.
+ * l[i:] (i > |l|-|s|).  Equal lengths: rapidfuzz evaluates both directions (windows of b against a,
+ * then windows of a against b) and keeps the better one; the two window sets differ, so both are
+ * evaluated here too.  Empty s: 100 if both empty else 0.
  * LOW-CONFIDENCE restatement: window policy recalled from the published sources. */
-double orc_partial_ratio(const cp_t *a, int64_t na, const cp_t *b, int64_t nb)
+static double partial_one_way(const cp_t *s, int64_t ns, const cp_t *l, int64_t nl)
 {
-    const cp_t *s = a, *l = b; int64_t ns = na, nl = nb;
-    if (ns > nl) { s = b; ns = nb; l = a; nl = na; }
-    if (ns == 0) return nl == 0 ? 100.0 : 0.0;
     double best = 0.0;
     for (int64_t i = 1; i < ns; ++i) {                       /* prefixes shorter than |s| */
         double r = orc_ratio(s, ns, l, i);
@@ -352,6 +350,19 @@ double orc_partial_ratio(const cp_t *a, int64_t na, const cp_t *b, int64_t nb)
     }
     for (int64_t i = nl - ns + 1; i < nl; ++i) {             /* suffixes shorter than |s| */
         double r = orc_ratio(s, ns, l + i, nl - i);
+        if (r > best) best = r;
+    }
+    return best;
+}
+
+double orc_partial_ratio(const cp_t *a, int64_t na, const cp_t *b, int64_t nb)
+{
+    const cp_t *s = a, *l = b; int64_t ns = na, nl = nb;
+    if (ns > nl) { s = b; ns = nb; l = a; nl = na; }
+    if (ns == 0) return nl == 0 ? 100.0 : 0.0;
+    double best = partial_one_way(s, ns, l, nl);
+    if (ns == nl) {
+        double r = partial_one_way(l, nl, s, ns);
         if (r > best) best = r;
     }
     return best;

@@ -125,3 +125,16 @@ def test_topk_many_ties_walk(oracle, runner, tmp_path):
     for qi, q in enumerate(["aa bb", "cc dd"]):
         exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, 35, 12)
         assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == exp
+
+
+def test_partial_ratio(oracle, runner, tmp_path):
+    import random
+    rnd = random.Random(23)
+    cps, offs = synth.make_corpus(150, max_chars=48, seed=21, vocab_size=30)
+    cand = synth.to_strings(cps, offs) + ["", "a", "ab", "abc abc", "x" * 70]
+    cand += ["".join(rnd.choice("abc ") for _ in range(rnd.randint(1, 12))) for _ in range(60)]
+    queries = ["", "a", "abc", "b a c", cand[3], cand[3][:9], "abcabcabca", "x" * 33, "xy" * 40] + synth.make_queries(cps, offs, 3, seed=22, max_chars=48)
+    got = _run(runner, tmp_path, 0, 3, cand, queries)
+    exp = _oracle_scores(oracle, oracle.PARTIAL, queries, cand)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:8]]

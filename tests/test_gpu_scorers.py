@@ -104,6 +104,30 @@ def test_golden_ratio_token_sort():
             qs = [r["q"] for r in chunk]
             r1 = c.score_all(qs, _lib.RATIO)
             r2 = c.score_all(qs, _lib.TOKEN_SORT)
+            r3 = c.score_all(qs, _lib.PARTIAL)
             for j, r in enumerate(chunk):
                 assert int(r1[j, lo + j]) == r["ratio"], r
                 assert int(r2[j, lo + j]) == r["token_sort"], r
+                if r["partial"] is not None:
+                    assert int(r3[j, lo + j]) == r["partial"], r
+
+
+def test_partial_ratio(oracle):
+    """fuzz.partial_ratio (reference app.py:1023): every window of the longer string, both directions
+    at equal lengths; needles shorter and longer than the candidates, multi-word patterns, top-k."""
+    rnd = random.Random(61)
+    cps, offs = synth.make_corpus(1500, max_chars=48, seed=62, vocab_size=120)
+    cand = synth.to_strings(cps, offs) + ["", "a", "ab", "x" * 70, "abc abc"]
+    cand += ["".join(rnd.choice("abc ") for _ in range(rnd.randint(1, 14))) for _ in range(300)]
+    queries = ["", "a", "abc", "b a c", cand[3], cand[3][:9], "abcabcabca", "x" * 33, "xy" * 40]
+    queries += synth.make_queries(cps, offs, 10, seed=63, max_chars=48)
+    buf, o = oracle.pack(cand)
+    with Corpus.from_prepared(cand) as c:
+        got = c.score_all(queries, _lib.PARTIAL)
+        exp = np.stack([oracle.score_all(oracle.PARTIAL, q, buf, o) for q in queries]).astype(np.uint8)
+        bad = np.argwhere(got != exp)
+        assert bad.size == 0, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]]
+        idx, score, cnt = c.topk(queries[:8], 60, 9, _lib.PARTIAL)
+        for qi in range(8):
+            e = oracle.topk(oracle.PARTIAL, queries[qi], buf, o, 60, 9)
+            assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == e

@@ -11,6 +11,7 @@
 #define FZ_MODE_RATIO 1
 #define FZ_MODE_INDEL 2
 #define FZ_MODE_LEV 3
+#define FZ_MODE_PARTIAL 4
 #define FZ_IDX_BITS 40
 #define FZ_IDX_MASK ((1ull << FZ_IDX_BITS) - 1ull)
 

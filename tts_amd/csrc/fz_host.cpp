@@ -693,6 +693,7 @@ static int scorer_plan(int scorer, int *view, int *mode, FzTies *ties)
     case FZ_TOKEN_SET: *view = VIEW_SET; *mode = FZ_MODE_TOKEN_SET; *ties = g_ties_norm_distance; return FZ_OK;
     case FZ_RATIO: *view = VIEW_RAW; *mode = FZ_MODE_RATIO; *ties = g_ties_norm_sim; return FZ_OK;
     case FZ_TOKEN_SORT: *view = VIEW_SORT; *mode = FZ_MODE_RATIO; *ties = g_ties_norm_sim; return FZ_OK;
+    case FZ_PARTIAL: *view = VIEW_RAW; *mode = FZ_MODE_PARTIAL; *ties = g_ties_norm_sim; return FZ_OK;
     case FZ_LEVENSHTEIN:
         return fail(FZ_ERR_INVALID, "FZ_LEVENSHTEIN yields distances, not 0..100 scores: use fz_distance_all / fz_distance_batch");
     default:

@@ -239,6 +239,152 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 
 
 // ---------------------------------------------------------------------------------------------
+// partial_ratio kernel (thefuzz.fuzz.partial_ratio, reference app.py:1023)
+// ---------------------------------------------------------------------------------------------
+// rapidfuzz partial_ratio: with `s` the shorter and `l` the longer string, the best ratio(s, w) over
+// the windows w of l: every l[i:i+|s|], every proper prefix l[:i] and suffix l[i:] shorter than |s|
+// (equal lengths: both directions).  One candidate per lane, the query's Peq in LDS as in the general
+// kernel; the pattern is always the QUERY, the text always the CANDIDATE (LCS is symmetric):
+//   A  query is the needle (m <= clen): pass i runs the text window [i, i+m) from a fresh state; the
+//      padding symbols beyond a shorter candidate are no-ops, so the same uniform loop also yields
+//      the suffix windows.  Pass 0 evaluates the prefix windows after every step.
+//   B  candidate is the needle (clen <= m): pass i scans the whole candidate against the pattern
+//      with the bits below i masked off; the zeros of the state in bits [i, e) then count
+//      LCS(candidate, query[i:e]) (Hyyro: bit j is 0 iff row j added one to the LCS), which is the
+//      window [i, min(i+clen, m)); pass 0 gives every prefix window the same way.
+// The best window is the one with the largest LCS / (|s| + |w|), compared by cross-multiplication;
+// one exact rounding at the end ((1 - d/L) * 100, the ratio() formula).
+__device__ __forceinline__ void fz_partial_consider(uint32_t l, uint32_t L, uint32_t &bl, uint32_t &bL)
+{
+    if (l * bL > bl * L) { bl = l; bL = L; }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t *s_peq = lds;                                    // [alphabet][W]
+    const FzQuery q = p.queries[blockIdx.y];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < p.alphabet * (uint32_t)W; i += blockDim.x) s_peq[i] = p.qblob[q.peq_off + i];
+    __syncthreads();
+    const uint32_t m = q.m;
+
+    uint32_t t_end = (blockIdx.x + 1u) * p.tiles_per_block;
+    if (t_end > p.ntiles) t_end = p.ntiles;
+    for (uint32_t tix = blockIdx.x * p.tiles_per_block + wave; tix < t_end; tix += p.nwaves) {
+        const uint32_t tile = p.tile_list ? p.tile_list[tix] : tix;
+        const FzTile td = p.tiles[tile];
+        const uint32_t clen = td.ntok ? p.tokend[td.toff + lane] : 0u;   // raw view: one slot = the length
+        const uint32_t maxlen = (uint32_t)td.ndw * 4u;
+        const uint32_t *symp = p.sym + td.coff + lane;
+        const bool valid = m != 0u && clen != 0u;
+        const bool doA = valid && m <= clen, doB = valid && clen <= m;
+        uint32_t bl = 0u, bL = 1u;                             // best window so far: LCS bl, length sum bL
+
+        if (__ballot(doA) != 0ull) {
+            // ---- A: windows of the candidate, needle = query ---------------------------------
+            for (uint32_t i = 0; i < maxlen; ++i) {
+                if (__ballot(doA && i < clen) == 0ull) break;
+                uint32_t V[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w) V[w] = 0xFFFFFFFFu;
+                uint32_t jend = i + m;
+                if (jend > maxlen) jend = maxlen;
+                uint32_t cw = 0u;
+                for (uint32_t j = i; j < jend; ++j) {
+                    if (j == i || (j & 3u) == 0u) cw = symp[(j >> 2) * 64u];
+                    const uint32_t s = (cw >> (8u * (j & 3u))) & 0xFFu;
+                    const uint32_t *row = s_peq + s * (uint32_t)W;
+                    uint32_t carry = 0u;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const uint32_t u = V[w] & row[w];
+                        const uint64_t t = (uint64_t)V[w] + (uint64_t)u + (uint64_t)carry;
+                        carry = (uint32_t)(t >> 32);
+                        V[w] = (uint32_t)t | (V[w] ^ u);
+                    }
+                    if (i == 0u && j + 1u < m) {               // proper prefix window l[:j+1]
+                        uint32_t l = 0u;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) l += (uint32_t)__builtin_popcount(~V[w]);
+                        if (doA) fz_partial_consider(l, m + j + 1u, bl, bL);
+                    }
+                }
+                if (doA && i < clen) {
+                    uint32_t l = 0u;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) l += (uint32_t)__builtin_popcount(~V[w]);
+                    const uint32_t wl = clen - i < m ? clen - i : m;
+                    fz_partial_consider(l, m + wl, bl, bL);
+                }
+            }
+        }
+
+        if (__ballot(doB) != 0ull) {
+            // ---- B: windows of the query, needle = candidate ---------------------------------
+            for (uint32_t i = 0; i < m; ++i) {
+                uint32_t V[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w) V[w] = 0xFFFFFFFFu;
+                for (uint32_t d = 0; d < td.ndw; ++d) {
+                    const uint32_t cw = symp[d * 64u];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t s = (cw >> (8 * k)) & 0xFFu;
+                        const uint32_t *row = s_peq + s * (uint32_t)W;
+                        uint32_t carry = 0u;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) {
+                            // pattern bits below i are masked off: they belong to no window of this pass
+                            const uint32_t lo = (uint32_t)w * 32u;
+                            const uint32_t keep = i <= lo ? 0xFFFFFFFFu : (i >= lo + 32u ? 0u : (0xFFFFFFFFu << (i - lo)));
+                            const uint32_t u = V[w] & row[w] & keep;
+                            const uint64_t t = (uint64_t)V[w] + (uint64_t)u + (uint64_t)carry;
+                            carry = (uint32_t)(t >> 32);
+                            V[w] = (uint32_t)t | (V[w] ^ u);
+                        }
+                    }
+                }
+                if (doB) {
+                    const uint32_t e = i + clen < m ? i + clen : m;       // window query[i:e]
+                    uint32_t l = 0u;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const uint32_t lo = (uint32_t)w * 32u;
+                        const uint32_t ge = i <= lo ? 0xFFFFFFFFu : (i >= lo + 32u ? 0u : (0xFFFFFFFFu << (i - lo)));
+                        const uint32_t lt = e >= lo + 32u ? 0xFFFFFFFFu : (e <= lo ? 0u : ((1u << (e - lo)) - 1u));
+                        l += (uint32_t)__builtin_popcount(~V[w] & ge & lt);
+                    }
+                    fz_partial_consider(l, clen + (e - i), bl, bL);
+                }
+                if (i == 0u) {
+                    // proper prefix windows query[:j], j = 1 .. clen-1: running count of the zeros
+                    uint32_t cnt = 0u;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        if ((uint32_t)w * 32u < m) {
+                            const uint32_t z = ~V[w];
+                            for (uint32_t b = 0; b < 32u; ++b) {
+                                cnt += (z >> b) & 1u;
+                                const uint32_t j = (uint32_t)w * 32u + b + 1u;
+                                if (doB && j < clen) fz_partial_consider(cnt, clen + j, bl, bL);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        uint32_t sc;
+        if (!valid) sc = (m == 0u && clen == 0u) ? 100u : 0u;
+        else sc = fz_round_ratio(bL - 2u * bl, bL, p.ties);
+        p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // stream scoring kernel: short candidates as per-lane PATTERNS, queries streamed as wave-uniform TEXT
 // ---------------------------------------------------------------------------------------------
 // LCS is symmetric, so the roles of the general kernel are swapped here: one wave owns one tile, every
@@ -719,9 +865,22 @@ static hipError_t launch_general2(const FzScoreParams &p, dim3 grid, size_t lds,
 }
 
 template <int W>
+static hipError_t launch_partial(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_partial<W>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((fz_score_partial<W>), grid, dim3(p.nwaves * 64u), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int W>
 static hipError_t launch_general(int mode, const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
 {
     switch (mode) {
+    case FZ_MODE_PARTIAL: return launch_partial<W>(p, grid, lds, st);
     case FZ_MODE_TOKEN_SET: return launch_general2<W, FZ_MODE_TOKEN_SET>(p, grid, lds, st);
     case FZ_MODE_RATIO: return launch_general2<W, FZ_MODE_RATIO>(p, grid, lds, st);
     case FZ_MODE_INDEL: return launch_general2<W, FZ_MODE_INDEL>(p, grid, lds, st);
