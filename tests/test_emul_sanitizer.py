@@ -138,3 +138,35 @@ def test_partial_ratio(oracle, runner, tmp_path):
     exp = _oracle_scores(oracle, oracle.PARTIAL, queries, cand)
     bad = np.argwhere(got != exp)
     assert bad.size == 0, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:8]]
+
+
+def _wide_corpus(n, seed, max_tok=5):
+    """names over > 254 distinct code points (CJK, Arabic, Cyrillic, ASCII): forces 16-bit symbols"""
+    import random
+    rnd = random.Random(seed)
+    alpha = [chr(c) for c in range(0x4E00, 0x4E00 + 400)] + [chr(c) for c in range(0x0621, 0x064A)] + \
+            [chr(c) for c in range(0x0430, 0x0450)] + list("abcdefghij0123456789")
+    vocab = ["".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 6))) for _ in range(220)]
+    return [" ".join(rnd.choice(vocab) for _ in range(rnd.randint(1, max_tok))) for _ in range(n)], vocab
+
+
+def test_wide_alphabet_all_scorers(oracle, runner, tmp_path):
+    cand, vocab = _wide_corpus(260, 31)
+    cand += ["", vocab[0], "x" * 70, " ".join(vocab[:30])]
+    assert len(set("".join(cand))) > 300
+    queries = [cand[3], cand[10] + " " + vocab[5], vocab[7], "", "zz", "丁丂 abc", " ".join(vocab[10:32])]
+    for sk, orc in ((0, oracle.TOKEN_SET), (1, oracle.RATIO), (2, oracle.TOKEN_SORT), (3, oracle.PARTIAL)):
+        got = _run(runner, tmp_path, 0, sk, cand, queries)
+        exp = _oracle_scores(oracle, orc, queries, cand)
+        bad = np.argwhere(got != exp)
+        assert bad.size == 0, (sk, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])
+    for kind, fn in ((0, oracle.indel), (1, oracle.levenshtein)):
+        got = _run(runner, tmp_path, 1, kind, cand[:80], queries)
+        for qi, q in enumerate(queries):
+            for i, s in enumerate(cand[:80]):
+                assert int(got[qi, i]) == fn(q, s), (kind, q, s)
+    buf, o = oracle.pack(cand)
+    idx, score, cnt = _run(runner, tmp_path, 2, 0, cand, queries, min_score=35, k=6)
+    for qi, q in enumerate(queries):
+        exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, 35, 6)
+        assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == exp

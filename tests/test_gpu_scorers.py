@@ -131,3 +131,37 @@ def test_partial_ratio(oracle):
         for qi in range(8):
             e = oracle.topk(oracle.PARTIAL, queries[qi], buf, o, 60, 9)
             assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == e
+
+
+def _wide_corpus(n, seed, max_tok=5):
+    """names over > 254 distinct code points (CJK, Arabic, Cyrillic, ASCII): 16-bit symbols"""
+    rnd = random.Random(seed)
+    alpha = [chr(c) for c in range(0x4E00, 0x4E00 + 900)] + [chr(c) for c in range(0x0621, 0x064A)] + \
+            [chr(c) for c in range(0x0430, 0x0450)] + list("abcdefghij0123456789")
+    vocab = ["".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 6))) for _ in range(700)]
+    return [" ".join(rnd.choice(vocab) for _ in range(rnd.randint(1, max_tok))) for _ in range(n)], vocab
+
+
+def test_wide_alphabet_all_scorers(oracle):
+    """A corpus with more than 254 distinct code points (16-bit symbols, indirect Peq rows)."""
+    cand, vocab = _wide_corpus(2500, 71)
+    cand += ["", vocab[0], "x" * 70, " ".join(vocab[:40])]
+    assert len(set("".join(cand))) > 600
+    queries = [cand[3], cand[10] + " " + vocab[5], vocab[7], "", "zz", "丁丂 abc", " ".join(vocab[10:32]), cand[77][1:]]
+    buf, o = oracle.pack(cand)
+    with Corpus.from_prepared(cand) as c:
+        assert c.info()["alphabet_size"] > 256
+        for sc, orc in ((_lib.TOKEN_SET, oracle.TOKEN_SET), (_lib.RATIO, oracle.RATIO),
+                        (_lib.TOKEN_SORT, oracle.TOKEN_SORT), (_lib.PARTIAL, oracle.PARTIAL)):
+            got = c.score_all(queries, sc)
+            exp = np.stack([oracle.score_all(orc, q, buf, o) for q in queries]).astype(np.uint8)
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (sc, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])
+        idx, score, cnt = c.topk(queries, 35, 10)
+        for qi, q in enumerate(queries):
+            e = oracle.topk(oracle.TOKEN_SET, q, buf, o, 35, 10)
+            assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == e
+        lev = c.distance_all(queries[:3], 1)
+        for qi in range(3):
+            for i in range(0, len(cand), 37):
+                assert int(lev[qi, i]) == oracle.levenshtein(queries[qi], cand[i])

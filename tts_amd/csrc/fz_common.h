@@ -15,8 +15,8 @@
 #define FZ_IDX_BITS 40
 #define FZ_IDX_MASK ((1ull << FZ_IDX_BITS) - 1ull)
 
-// One 64-candidate tile.  Symbols: dword d of lane l at sym[coff + d*64 + l] (4 symbols per dword,
-// little endian).  Tokens: slot i of lane l at tokid[toff + i*64 + l] / tokend[toff + i*64 + l].
+// One 64-candidate tile.  Symbols: dword d of lane l at sym[coff + d*64 + l] (4 8-bit symbols per
+// dword, little endian; 2 16-bit symbols when the view is wide).  Tokens: slot i of lane l at tokid[toff + i*64 + l] / tokend[toff + i*64 + l].
 struct FzTile {
     uint32_t coff;   // dword offset into the symbol array
     uint32_t toff;   // element offset into the token arrays
@@ -32,7 +32,8 @@ struct FzQuery {
     uint32_t n_tok;      // all tokens of the query (0 => every score is 0)
     uint32_t m;          // pattern length: sum(len+1) over tokens (each token + one separator)
     uint32_t out_row;    // row of the score matrix this query writes
-    uint32_t pad0, pad1;
+    uint32_t map_off;    // wide alphabets: dword offset of the u16 symbol -> Peq row map [alphabet]
+    uint32_t peq_rows;   // rows of this query's Peq table (alphabet, or 1 + its distinct symbols when wide)
 };
 
 // Round-to-nearest tie tables (see fz_host.cpp make_tie_table): bit q says whether the exact value
@@ -48,7 +49,9 @@ struct FzScoreParams {
     const FzTile *tiles;
     uint32_t ntiles;
     uint32_t tiles_per_block;
-    uint32_t alphabet;        // rows of a Peq table
+    uint32_t alphabet;        // symbols of the corpus view (rows of a Peq table unless wide)
+    uint32_t peq_rows;        // LDS rows reserved for a Peq table: max over the queries of the launch
+    uint32_t wide;            // 1: 16-bit symbols, two per dword, Peq rows looked up through a map
     uint32_t pmax;            // capacity of the per-query token arrays in LDS
     uint32_t ntkw;            // text keep-mask words per lane (ceil(max ndw / 8))
     uint32_t nwaves;          // waves per block

@@ -108,9 +108,10 @@ enum { VIEW_SET = 0,    // sorted unique tokens, each followed by a separator  (
 
 struct View {
     bool built = false;
+    bool wide = false;                                    // > 254 distinct code points: 16-bit symbols
     uint32_t npad = 0, ntiles = 0, max_ndw = 0, max_len = 0, max_tok = 0, alphabet = 2;
     uint64_t total_symbols = 0, total_tokens = 0, device_bytes = 0;
-    std::vector<uint8_t> sym_of_cp;                       // code point -> symbol (0 = not in corpus)
+    std::vector<uint16_t> sym_of_cp;                      // code point -> symbol (0 = not in corpus)
     uint32_t *d_sym = nullptr, *d_tokid = nullptr, *d_orig_of_phys = nullptr, *d_phys_of_orig = nullptr;
     uint16_t *d_tokend = nullptr;
     FzTile *d_tiles = nullptr;
@@ -259,18 +260,20 @@ static int build_view(fz_corpus *c, int kind)
         for (uint64_t i = n ? offs[0] : 0; i < total; ++i) seen[cps[i]] = 1;
         v.sym_of_cp.assign(0x110000, 0);
         uint32_t next = 2;
-        if (kind == VIEW_SORT) v.sym_of_cp[0x20] = (uint8_t)FZ_SYM_SPACE;
+        if (kind == VIEW_SORT) v.sym_of_cp[0x20] = (uint16_t)FZ_SYM_SPACE;
         for (uint32_t cp = 0; cp < 0x110000u; ++cp) {
             if (!seen[cp]) continue;
             if (kind != VIEW_RAW && is_space(cp)) continue;       // separators never reach the text
-            if (next > 255u) return fail(FZ_ERR_ALPHABET, "corpus has more than 254 distinct code points; the 8-bit symbol table is full");
-            v.sym_of_cp[cp] = (uint8_t)next++;
+            if (next > 0xFFFFu) return fail(FZ_ERR_ALPHABET, "corpus has more than 65534 distinct code points; the 16-bit symbol table is full");
+            v.sym_of_cp[cp] = (uint16_t)next++;
         }
         v.alphabet = next;
+        v.wide = next > 256u;                                     // 8-bit symbols no longer suffice
     }
+    const uint32_t spd = v.wide ? 2u : 4u;                        // symbols per dword
 
     // ---- text of every candidate ------------------------------------------------------------
-    std::vector<uint8_t> canon;          // symbols, all candidates back to back
+    std::vector<uint16_t> canon;         // symbols, all candidates back to back
     std::vector<uint64_t> canon_off(n + 1, 0);
     std::vector<uint32_t> tok_id;        // VIEW_SET: token ids, all candidates back to back
     std::vector<uint16_t> tok_end;       // VIEW_SET: exclusive end (incl. separator) of each token
@@ -289,7 +292,7 @@ static int build_view(fz_corpus *c, int kind)
                 split_sorted(s, sl, kind == VIEW_SET, toks);
                 for (size_t ti = 0; ti < toks.size(); ++ti) {
                     Tok t = toks[ti];
-                    if (kind == VIEW_SORT && ti) { canon.push_back((uint8_t)FZ_SYM_SPACE); ++len; }
+                    if (kind == VIEW_SORT && ti) { canon.push_back((uint16_t)FZ_SYM_SPACE); ++len; }
                     for (char32_t ch : t) canon.push_back(v.sym_of_cp[(uint32_t)ch]);
                     len += t.size();
                     if (kind == VIEW_SET) {
@@ -303,7 +306,7 @@ static int build_view(fz_corpus *c, int kind)
                         } else {
                             id = it->second;
                         }
-                        canon.push_back((uint8_t)FZ_SYM_SPACE);
+                        canon.push_back((uint16_t)FZ_SYM_SPACE);
                         len += 1;
                         tok_id.push_back(id);
                         tok_end.push_back((uint16_t)std::min<uint64_t>(len, 0xFFFF));
@@ -326,7 +329,7 @@ static int build_view(fz_corpus *c, int kind)
     v.npad = v.ntiles * FZ_TILE;
     std::vector<uint64_t> keys(n);
     for (uint64_t i = 0; i < n; ++i) {
-        uint64_t ndw = (canon_off[i + 1] - canon_off[i] + 3) / 4, nt = tok_off[i + 1] - tok_off[i];
+        uint64_t ndw = (canon_off[i + 1] - canon_off[i] + spd - 1) / spd, nt = tok_off[i + 1] - tok_off[i];
         keys[i] = (ndw << 48) | (std::min<uint64_t>(nt, 0xFFFF) << 32) | i;
     }
     std::sort(keys.begin(), keys.end());
@@ -345,7 +348,7 @@ static int build_view(fz_corpus *c, int kind)
             uint64_t ph = (uint64_t)t * FZ_TILE + l;
             if (ph >= n) break;
             uint32_t o = v.h_orig_of_phys[ph];
-            ndw = std::max<uint32_t>(ndw, (uint32_t)((canon_off[o + 1] - canon_off[o] + 3) / 4));
+            ndw = std::max<uint32_t>(ndw, (uint32_t)((canon_off[o + 1] - canon_off[o] + spd - 1) / spd));
             ntok = std::max<uint32_t>(ntok, (uint32_t)(tok_off[o + 1] - tok_off[o]));
         }
         if (ntok > 0xFFFFu) return fail(FZ_ERR_LIMIT, "a candidate has more than 65535 tokens");
@@ -368,9 +371,9 @@ static int build_view(fz_corpus *c, int kind)
                 uint32_t o = v.h_orig_of_phys[ph];
                 len = (uint32_t)(canon_off[o + 1] - canon_off[o]);
                 nt = (uint32_t)(tok_off[o + 1] - tok_off[o]);
-                const uint8_t *src = canon.data() + canon_off[o];
+                const uint16_t *src = canon.data() + canon_off[o];
                 for (uint32_t j = 0; j < len; ++j)
-                    h_sym[td.coff + (uint64_t)(j >> 2) * 64 + l] |= (uint32_t)src[j] << (8 * (j & 3));
+                    h_sym[td.coff + (uint64_t)(j / spd) * 64 + l] |= (uint32_t)src[j] << ((32u / spd) * (j % spd));
                 for (uint32_t i = 0; i < nt; ++i) {
                     h_tokid[td.toff + (uint64_t)i * 64 + l] = tok_id[tok_off[o] + i];
                     h_tokend[td.toff + (uint64_t)i * 64 + l] = tok_end[tok_off[o] + i];
@@ -389,8 +392,9 @@ static int build_view(fz_corpus *c, int kind)
     if ((rc = upload(&v.d_phys_of_orig, phys_of_orig, &v.device_bytes)) != FZ_OK) return rc;
     std::vector<uint32_t> ts1, ts2, tslow;
     for (uint32_t t = 0; t < v.ntiles; ++t) {
-        if (tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
-        else if (tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
+        // the stream kernel keeps one Peq row per symbol byte: 8-bit symbols only
+        if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
+        else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
         else tslow.push_back(t);
     }
     v.n_s1 = (uint32_t)ts1.size(); v.n_s2 = (uint32_t)ts2.size(); v.n_slow = (uint32_t)tslow.size();
@@ -589,8 +593,9 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
                 auto it = c->vocab.find(t);
                 if (it != c->vocab.end()) trips.push_back({it->second, (uint32_t)pat.size(), (uint32_t)t.size() + 1u});
                 ids.push_back(it != c->vocab.end() ? it->second : FZ_QTOK_UNKNOWN);
-                for (char32_t ch : t)
-                    if (uint32_t sy = sym_of((uint32_t)ch)) text.push_back((uint8_t)sy);
+                if (b.allow_stream)
+                    for (char32_t ch : t)
+                        if (uint32_t sy = sym_of((uint32_t)ch)) text.push_back((uint8_t)sy);
                 tok_first.push_back((uint32_t)text.size());
             }
             pat.append(t);
@@ -600,10 +605,11 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
     const uint64_t m = pat.size();
     if (m > FZ_MAX_PATTERN) return fail(FZ_ERR_TOO_LONG, "query pattern of %llu code points exceeds FZ_MAX_PATTERN (%u)", (unsigned long long)m, FZ_MAX_PATTERN);
     if (kind != VIEW_SET) {                    // one pseudo token: the whole text, no separator steps
-        for (char32_t ch : pat) {
-            const uint32_t sy = (kind == VIEW_SORT && ch == U' ') ? FZ_SYM_SPACE : sym_of((uint32_t)ch);
-            if (sy) text.push_back((uint8_t)sy);
-        }
+        if (b.allow_stream)
+            for (char32_t ch : pat) {
+                const uint32_t sy = (kind == VIEW_SORT && ch == U' ') ? FZ_SYM_SPACE : sym_of((uint32_t)ch);
+                if (sy) text.push_back((uint8_t)sy);
+            }
         tok_first.push_back((uint32_t)text.size());
         ids.push_back(FZ_QTOK_UNKNOWN);
     }
@@ -613,19 +619,44 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
 
     const int W = fz_pick_width((uint32_t)m);
     FzQuery q{};
-    q.peq_off = (uint32_t)b.peq.size();
     q.tok_off = (uint32_t)b.tok_id.size();
     q.n_tok = ntok;
     q.m = (uint32_t)m;
     q.out_row = out_row;
-    b.peq.resize(b.peq.size() + (size_t)v.alphabet * W, 0u);
-    uint32_t *peq = b.peq.data() + q.peq_off;
-    for (uint32_t bit = 0; bit < m; ++bit) {
-        uint32_t cp = (uint32_t)pat[bit];
-        uint32_t sym;
-        if (kind == VIEW_SET && cp == 0x20u) sym = FZ_SYM_SPACE;       // the separators just added
-        else sym = sym_of(cp);
-        if (sym) peq[sym * W + (bit >> 5)] |= 1u << (bit & 31u);
+    auto pat_sym = [&](uint32_t bit) -> uint32_t {
+        const uint32_t cp = (uint32_t)pat[bit];
+        if (kind == VIEW_SET && cp == 0x20u) return FZ_SYM_SPACE;       // the separators just added
+        return sym_of(cp);
+    };
+    if (!v.wide) {
+        q.peq_off = (uint32_t)b.peq.size();
+        q.peq_rows = v.alphabet;
+        b.peq.resize(b.peq.size() + (size_t)v.alphabet * W, 0u);
+        uint32_t *peq = b.peq.data() + q.peq_off;
+        for (uint32_t bit = 0; bit < m; ++bit)
+            if (const uint32_t sym = pat_sym(bit)) peq[sym * W + (bit >> 5)] |= 1u << (bit & 31u);
+    } else {
+        // wide alphabet: a u16 map symbol -> row, and a table with one row per distinct symbol of THIS
+        // pattern; row 0 stays all zero and stands for every other symbol (FZ_SYM_NULL included)
+        q.map_off = (uint32_t)b.peq.size();
+        b.peq.resize(b.peq.size() + ((size_t)v.alphabet + 1) / 2, 0u);
+        uint32_t nrows = 1;
+        std::vector<uint32_t> row_of_bit(m, 0u);
+        {
+            uint16_t *map = reinterpret_cast<uint16_t *>(b.peq.data() + q.map_off);
+            for (uint32_t bit = 0; bit < m; ++bit) {
+                const uint32_t sym = pat_sym(bit);
+                if (!sym) continue;
+                if (!map[sym]) map[sym] = (uint16_t)nrows++;
+                row_of_bit[bit] = map[sym];
+            }
+        }
+        q.peq_off = (uint32_t)b.peq.size();
+        q.peq_rows = nrows;
+        b.peq.resize(b.peq.size() + (size_t)nrows * W, 0u);
+        uint32_t *peq = b.peq.data() + q.peq_off;
+        for (uint32_t bit = 0; bit < m; ++bit)
+            if (row_of_bit[bit]) peq[row_of_bit[bit] * W + (bit >> 5)] |= 1u << (bit & 31u);
     }
     std::sort(trips.begin(), trips.end(), [](const Trip &a, const Trip &b2) { return a.id < b2.id; });
     q.n_ids = (uint32_t)trips.size();
@@ -815,10 +846,16 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             p.ntiles = l.slow_only ? v.n_slow : v.ntiles;
             p.tile_list = l.slow_only ? v.d_tiles_slow : nullptr;
             p.alphabet = v.alphabet;
-            uint32_t pmax = 1;
-            for (uint32_t i = 0; i < count; ++i) pmax = std::max(pmax, qlist[first + i].n_ids);
+            p.wide = v.wide ? 1u : 0u;
+            uint32_t pmax = 1, peq_rows = 1;
+            for (uint32_t i = 0; i < count; ++i) {
+                pmax = std::max(pmax, qlist[first + i].n_ids);
+                peq_rows = std::max(peq_rows, qlist[first + i].peq_rows);
+            }
             p.pmax = pmax;
-            p.ntkw = std::max<uint32_t>(1, (v.max_ndw + 7) / 8);
+            p.peq_rows = peq_rows;
+            const uint32_t tkd = v.wide ? 16u : 8u;             // symbol dwords per text keep-mask word
+            p.ntkw = std::max<uint32_t>(1, (v.max_ndw + tkd - 1) / tkd);
             p.nwaves = 4;
             while (p.nwaves > 1 && fz_score_lds_bytes(W, p) > 64 * 1024) p.nwaves >>= 1;
             if (fz_score_lds_bytes(W, p) > 160 * 1024)

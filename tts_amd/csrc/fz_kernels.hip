@@ -88,21 +88,38 @@ __device__ __forceinline__ void fz_clear_bits(uint32_t *row, uint32_t s, uint32_
 //       FZ_MODE_RATIO      plain InDel ratio of pattern vs text, thefuzz ratio()/token_sort (u8)
 //       FZ_MODE_INDEL      raw InDel distance (u16)
 //       FZ_MODE_LEV        raw uniform-cost Levenshtein distance, Myers/Hyyro Pv/Mv recurrence (u16)
-template <int W, int MODE>
+// WIDE: the corpus has more than 254 distinct code points, so its symbols are 16 bits (two per
+//       dword) and the Peq table is indirect: a u16 map [alphabet] -> row of a table that only holds
+//       the symbols of THIS query (row 0 = all zero = every other symbol), both in LDS.
+template <bool WIDE>
+struct FzSym {
+    static constexpr int SPD = WIDE ? 2 : 4;                  // symbols per dword
+    static constexpr int BITS = WIDE ? 16 : 8;
+    static constexpr uint32_t MASK = WIDE ? 0xFFFFu : 0xFFu;
+    static constexpr uint32_t TKD = 32u / (uint32_t)SPD;      // symbol dwords covered by one keep-mask word
+};
+
+template <int W, int MODE, bool WIDE>
 __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 {
+    using SY = FzSym<WIDE>;
     extern __shared__ __align__(16) uint32_t lds[];
-    uint32_t *s_peq = lds;                                    // [alphabet][W]
-    uint32_t *s_qid = s_peq + p.alphabet * W;                 // [pmax] query token ids, ascending
+    uint32_t *s_peq = lds;                                    // [peq_rows][W]
+    uint32_t *s_qid = s_peq + p.peq_rows * W;                 // [pmax] query token ids, ascending
     uint32_t *s_qpos = s_qid + p.pmax;                        // first pattern bit of the token
     uint32_t *s_qlen = s_qpos + p.pmax;                       // token length + 1
     uint32_t *s_M = s_qlen + p.pmax;                          // [nwaves][W][64] pattern keep masks
     uint32_t *s_TK = s_M + p.nwaves * (uint32_t)W * 64u;      // [nwaves][ntkw][64] text keep masks
+    const uint16_t *s_map = reinterpret_cast<const uint16_t *>(s_TK + p.nwaves * p.ntkw * 64u);   // WIDE: [alphabet]
 
     const FzQuery q = p.queries[blockIdx.y];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-    for (uint32_t i = tid; i < p.alphabet * (uint32_t)W; i += blockDim.x) s_peq[i] = p.qblob[q.peq_off + i];
+    for (uint32_t i = tid; i < q.peq_rows * (uint32_t)W; i += blockDim.x) s_peq[i] = p.qblob[q.peq_off + i];
+    if (WIDE) {
+        uint32_t *m32 = s_TK + p.nwaves * p.ntkw * 64u;
+        for (uint32_t i = tid; i < (p.alphabet + 1u) / 2u; i += blockDim.x) m32[i] = p.qblob[q.map_off + i];
+    }
     for (uint32_t i = tid; i < q.n_ids; i += blockDim.x) {
         s_qid[i] = p.qtok_id[q.tok_off + i];
         s_qpos[i] = p.qtok_pos[q.tok_off + i];
@@ -119,7 +136,7 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
     for (uint32_t tix = blockIdx.x * p.tiles_per_block + wave; tix < t_end; tix += p.nwaves) {
         const uint32_t tile = p.tile_list ? p.tile_list[tix] : tix;
         const FzTile td = p.tiles[tile];
-        const uint32_t ntkw = ((uint32_t)td.ndw + 7u) >> 3;
+        const uint32_t ntkw = ((uint32_t)td.ndw + SY::TKD - 1u) / SY::TKD;
 
 #pragma unroll
         for (int w = 0; w < W; ++w) Mrow[w * 64] = 0xFFFFFFFFu;
@@ -163,10 +180,10 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
             for (uint32_t d = 0; d < td.ndw; ++d) {
                 const uint32_t cw = symp[d * 64u];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (d * 4u + (uint32_t)k < clen && q.m != 0u) {     // padding is not text here
-                        const uint32_t s = (cw >> (8 * k)) & 0xFFu;
-                        const uint32_t *row = s_peq + s * (uint32_t)W;
+                for (int k = 0; k < SY::SPD; ++k) {
+                    if (d * (uint32_t)SY::SPD + (uint32_t)k < clen && q.m != 0u) {     // padding is not text here
+                        const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
+                        const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
                         uint32_t carry = 0u, phc = 1u, mhc = 0u;
 #pragma unroll
                         for (int w = 0; w < W; ++w) {
@@ -200,12 +217,12 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
         uint32_t tkw = 0u;
         for (uint32_t d = 0; d < td.ndw; ++d) {
             const uint32_t cw = symp[d * 64u];
-            if ((d & 7u) == 0u) tkw = TKrow[(d >> 3) * 64u];
+            if ((d % SY::TKD) == 0u) tkw = TKrow[(d / SY::TKD) * 64u];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t s = (cw >> (8 * k)) & 0xFFu;
+            for (int k = 0; k < SY::SPD; ++k) {
+                uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
                 if (((tkw >> k) & 1u) == 0u) s = FZ_SYM_NULL;  // removed token: no match, no change
-                const uint32_t *row = s_peq + s * (uint32_t)W;
+                const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
                 uint32_t carry = 0u;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
                     V[w] = (uint32_t)t | (V[w] ^ u);
                 }
             }
-            tkw >>= 4;
+            tkw >>= SY::SPD;
         }
         uint32_t lcs1 = 0u;
 #pragma unroll
@@ -259,14 +276,20 @@ __device__ __forceinline__ void fz_partial_consider(uint32_t l, uint32_t L, uint
     if (l * bL > bl * L) { bl = l; bL = L; }
 }
 
-template <int W>
+template <int W, bool WIDE>
 __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
 {
+    using SY = FzSym<WIDE>;
     extern __shared__ __align__(16) uint32_t lds[];
-    uint32_t *s_peq = lds;                                    // [alphabet][W]
+    uint32_t *s_peq = lds;                                    // [peq_rows][W]
+    // same LDS layout as fz_score_general (fz_score_lds_bytes): the map sits behind the mask arrays
+    uint32_t *m32 = s_peq + p.peq_rows * W + 3u * p.pmax + p.nwaves * 64u * ((uint32_t)W + p.ntkw);
+    const uint16_t *s_map = reinterpret_cast<const uint16_t *>(m32);
     const FzQuery q = p.queries[blockIdx.y];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t i = tid; i < p.alphabet * (uint32_t)W; i += blockDim.x) s_peq[i] = p.qblob[q.peq_off + i];
+    for (uint32_t i = tid; i < q.peq_rows * (uint32_t)W; i += blockDim.x) s_peq[i] = p.qblob[q.peq_off + i];
+    if (WIDE)
+        for (uint32_t i = tid; i < (p.alphabet + 1u) / 2u; i += blockDim.x) m32[i] = p.qblob[q.map_off + i];
     __syncthreads();
     const uint32_t m = q.m;
 
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
         const uint32_t tile = p.tile_list ? p.tile_list[tix] : tix;
         const FzTile td = p.tiles[tile];
         const uint32_t clen = td.ntok ? p.tokend[td.toff + lane] : 0u;   // raw view: one slot = the length
-        const uint32_t maxlen = (uint32_t)td.ndw * 4u;
+        const uint32_t maxlen = (uint32_t)td.ndw * (uint32_t)SY::SPD;
         const uint32_t *symp = p.sym + td.coff + lane;
         const bool valid = m != 0u && clen != 0u;
         const bool doA = valid && m <= clen, doB = valid && clen <= m;
@@ -293,9 +316,9 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
                 if (jend > maxlen) jend = maxlen;
                 uint32_t cw = 0u;
                 for (uint32_t j = i; j < jend; ++j) {
-                    if (j == i || (j & 3u) == 0u) cw = symp[(j >> 2) * 64u];
-                    const uint32_t s = (cw >> (8u * (j & 3u))) & 0xFFu;
-                    const uint32_t *row = s_peq + s * (uint32_t)W;
+                    if (j == i || (j % (uint32_t)SY::SPD) == 0u) cw = symp[(j / (uint32_t)SY::SPD) * 64u];
+                    const uint32_t s = (cw >> ((uint32_t)SY::BITS * (j % (uint32_t)SY::SPD))) & SY::MASK;
+                    const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
                     uint32_t carry = 0u;
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
@@ -330,9 +353,9 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
                 for (uint32_t d = 0; d < td.ndw; ++d) {
                     const uint32_t cw = symp[d * 64u];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t s = (cw >> (8 * k)) & 0xFFu;
-                        const uint32_t *row = s_peq + s * (uint32_t)W;
+                    for (int k = 0; k < SY::SPD; ++k) {
+                        const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
+                        const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
                         uint32_t carry = 0u;
 #pragma unroll
                         for (int w = 0; w < W; ++w) {
@@ -849,31 +872,44 @@ int fz_pick_width(uint32_t m)
 
 size_t fz_score_lds_bytes(int W, const FzScoreParams &p)
 {
-    return 4ull * ((size_t)p.alphabet * W + 3ull * p.pmax + (size_t)p.nwaves * 64ull * ((size_t)W + p.ntkw));
+    return 4ull * ((size_t)p.peq_rows * W + 3ull * p.pmax + (size_t)p.nwaves * 64ull * ((size_t)W + p.ntkw) +
+                   (p.wide ? ((size_t)p.alphabet + 1ull) / 2ull : 0ull));
+}
+
+template <int W, int MODE, bool WIDE>
+static hipError_t launch_general3(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_general<W, MODE, WIDE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((fz_score_general<W, MODE, WIDE>), grid, dim3(p.nwaves * 64u), lds, st, p);
+    return hipGetLastError();
 }
 
 template <int W, int MODE>
 static hipError_t launch_general2(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
 {
+    return p.wide ? launch_general3<W, MODE, true>(p, grid, lds, st) : launch_general3<W, MODE, false>(p, grid, lds, st);
+}
+
+template <int W, bool WIDE>
+static hipError_t launch_partial2(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
+{
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_general<W, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_partial<W, WIDE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((fz_score_general<W, MODE>), grid, dim3(p.nwaves * 64u), lds, st, p);
+    hipLaunchKernelGGL((fz_score_partial<W, WIDE>), grid, dim3(p.nwaves * 64u), lds, st, p);
     return hipGetLastError();
 }
 
 template <int W>
 static hipError_t launch_partial(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
 {
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_partial<W>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((fz_score_partial<W>), grid, dim3(p.nwaves * 64u), lds, st, p);
-    return hipGetLastError();
+    return p.wide ? launch_partial2<W, true>(p, grid, lds, st) : launch_partial2<W, false>(p, grid, lds, st);
 }
 
 template <int W>
