@@ -47,6 +47,12 @@ typedef enum {
     FZ_LEVENSHTEIN = 4  /* uniform-cost Levenshtein similarity -- reference app.py:296-317,429-432 */
 } fz_scorer;
 
+/* OR into `scorer` of fz_query_topk / fz_query_topk_keys: every candidate that passes min_score
+ * counts as a tie, so the results are the FIRST k passing candidates in list order (their score is
+ * reported as min_score).  Stands in for the first-hit scan of the reference's weighted FuzzySearch,
+ * `for ...: if fuzz.ratio(q, item) > 98: return item` (reference app.py:1009-1011). */
+#define FZ_ORDER_BY_INDEX 0x100
+
 /* limits */
 #define FZ_MAX_K 1024u            /* top-k size */
 #define FZ_MAX_PATTERN 1024u      /* query pattern length in code points incl. token separators */
@@ -136,6 +142,23 @@ int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, u
 int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                        int scorer, int32_t min_score, uint32_t k, uint64_t *out_keys_device,
                        uint32_t *out_cnt_device, int sync);
+
+/*
+ * fz_query_topk_pair -- the scoring loop of the reference's WEIGHTED FuzzySearch (app.py:995-1002,
+ * 1014-1032): score = partial_ratio/100*0.5 + token_set_ratio/100*0.5, capped at 0.99, kept if
+ * >= threshold, stable sort descending, slice top_n.  The two scorers see different forms of the
+ * same candidate (partial_ratio the normalised string, token_set_ratio its full_process-ed form),
+ * hence two corpora `ca`, `cb` over the same list (same n and base index, same device) and two
+ * packed query lists.  The fp64 expression is evaluated by the HOST LANGUAGE for all 101 x 101
+ * integer score pairs and passed as ranks: rank_tab[a*101 + b] = rank of the value among the
+ * distinct values (larger = better), min_rank = smallest rank whose value passes the threshold.
+ *   out_idx  : nq*k global indices, row q ordered by (rank desc, index asc)
+ *   out_rank : nq*k ranks (the caller maps a rank back to its fp64 value)
+ */
+int fz_query_topk_pair(fz_corpus *ca, int scorer_a, const uint32_t *qa_cps, const uint64_t *qa_offs,
+                       fz_corpus *cb, int scorer_b, const uint32_t *qb_cps, const uint64_t *qb_offs,
+                       uint32_t nq, const uint16_t *rank_tab, uint32_t min_rank, uint32_t k,
+                       uint64_t *out_idx, int32_t *out_rank, uint32_t *out_cnt);
 
 /*
  * fz_merge_topk -- deterministic merge of n_lists per-shard key lists (each nq*k keys as written

@@ -274,3 +274,47 @@ def c_find_best_matches(items: List[str], query: str, threshold: float, top_n: i
     q = full_process(query.lower())
     res = topk(scorer, q, buf, offs, min_score_for_threshold(threshold), top_n)
     return [(items[i], s / 100.0) for i, s in res]
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's WEIGHTED FuzzySearch (app.py:949-1032), statement for statement over the C scorers
+# ----------------------------------------------------------------------------------------------
+def weighted_normalize_string(s) -> str:
+    """app.py:974-979"""
+    if not isinstance(s, str):
+        return ""
+    return s.lower().replace('\u00d7', 'x').replace('\u00d7', 'x').strip()
+
+
+def weighted_score(query_norm: str, item_norm: str) -> float:
+    """app.py:1014-1032.  thefuzz: partial_ratio does not preprocess, token_set_ratio does."""
+    if query_norm == item_norm:
+        return 1.0
+    partial_score = score(PARTIAL, query_norm, item_norm) / 100.0
+    token_set_score = score(TOKEN_SET, full_process(query_norm), full_process(item_norm)) / 100.0
+    sc = (partial_score * 0.5) + (token_set_score * 0.5)
+    return min(sc, 0.99)
+
+
+def weighted_find_best_matches(items: List[str], query: str, threshold: float = 0.70,
+                               exact_match_threshold: float = 0.98, top_n: int = 10):
+    """app.py:981-1012 for one entity list."""
+    items_map = {weighted_normalize_string(p): p for p in items}
+    query_normalized = weighted_normalize_string(query)
+    exact_match = None
+    if query_normalized in items_map:
+        exact_match = items_map[query_normalized]
+    else:
+        for norm_item, original_item in items_map.items():
+            if score(RATIO, query_normalized, norm_item) > (exact_match_threshold * 100):
+                exact_match = original_item
+                break
+    if exact_match:
+        return [(exact_match, 1.0)]
+    matches = []
+    for normalized_item, original_item in items_map.items():
+        final_score = weighted_score(query_normalized, normalized_item)
+        if final_score >= threshold:
+            matches.append((original_item, final_score))
+    matches.sort(key=lambda x: x[1], reverse=True)
+    return matches[:top_n]

@@ -4,6 +4,7 @@
 //              u32 cps[ncps], u64 offs[n+1], u32 qcps[nqcps], u64 qoffs[nq+1]
 //   op 0 fz_score_all -> u8[nq*n];  op 1 fz_distance_all -> u16[nq*n];
 //   op 2 fz_query_topk -> u64 idx[nq*k], i32 score[nq*k], u32 cnt[nq]
+//   op 3 fz_query_topk_pair (scorer a | scorer b << 8; second corpus, queries and rank table appended) -> as op 2
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,6 +31,12 @@ int main(int argc, char **argv)
     const int32_t min_score = (int32_t)(int64_t)h[3];
     std::vector<uint32_t> cps, qcps; std::vector<uint64_t> offs, qoffs;
     if (!rd(f, cps, ncps) || !rd(f, offs, n + 1) || !rd(f, qcps, nqcps) || !rd(f, qoffs, nq + 1)) { fprintf(stderr, "short case file\n"); return 2; }
+    std::vector<uint32_t> cps_b, qcps_b; std::vector<uint64_t> offs_b, qoffs_b; std::vector<uint16_t> rank_tab;
+    if (op == 3) {          // fz_query_topk_pair: second corpus, second query list, rank table follow
+        uint64_t hb[2];
+        if (fread(hb, 8, 2, f) != 2 || !rd(f, cps_b, hb[0]) || !rd(f, offs_b, n + 1) || !rd(f, qcps_b, hb[1]) ||
+            !rd(f, qoffs_b, nq + 1) || !rd(f, rank_tab, 101 * 101)) { fprintf(stderr, "short pair case\n"); return 2; }
+    }
     fclose(f);
 
     fz_corpus *c = nullptr;
@@ -45,6 +52,17 @@ int main(int argc, char **argv)
         std::vector<uint16_t> out(nq * n ? nq * n : 1);
         rc = fz_distance_all(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, out.data());
         if (rc == FZ_OK) fwrite(out.data(), 2, nq * n, o);
+    } else if (op == 3) {
+        fz_corpus *cb = nullptr;
+        rc = fz_corpus_create(cps_b.data(), offs_b.data(), n, 0, 0, &cb);
+        if (rc != FZ_OK) { fprintf(stderr, "fz_corpus_create(b): %d %s\n", rc, fz_last_error()); return 3; }
+        std::vector<uint64_t> idx(nq * k ? nq * k : 1);
+        std::vector<int32_t> rk(nq * k ? nq * k : 1);
+        std::vector<uint32_t> cnt(nq ? nq : 1);
+        rc = fz_query_topk_pair(c, (int)(sk & 0xFF), qcps.data(), qoffs.data(), cb, (int)(sk >> 8), qcps_b.data(), qoffs_b.data(),
+                                (uint32_t)nq, rank_tab.data(), (uint32_t)h[3], (uint32_t)k, idx.data(), rk.data(), cnt.data());
+        if (rc == FZ_OK) { fwrite(idx.data(), 8, nq * k, o); fwrite(rk.data(), 4, nq * k, o); fwrite(cnt.data(), 4, nq, o); }
+        fz_corpus_destroy(cb);
     } else {
         std::vector<uint64_t> idx(nq * k ? nq * k : 1);
         std::vector<int32_t> sc(nq * k ? nq * k : 1);

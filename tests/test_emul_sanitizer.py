@@ -170,3 +170,73 @@ def test_wide_alphabet_all_scorers(oracle, runner, tmp_path):
     for qi, q in enumerate(queries):
         exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, 35, 6)
         assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == exp
+
+
+def _run_pair(runner, tmp_path, cand_a, cand_b, q_a, q_b, tab, min_rank, k):
+    """op 3: fz_query_topk_pair(PARTIAL on corpus a, TOKEN_SET on corpus b)."""
+    ca, oa = pack_prepared(list(cand_a)); cb, ob = pack_prepared(list(cand_b))
+    qa, qoa = pack_prepared(list(q_a)); qb, qob = pack_prepared(list(q_b))
+    n, nq = len(oa) - 1, len(qoa) - 1
+    case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
+    with open(case, "wb") as f:
+        np.array([MAGIC, 3, 3 | (0 << 8), min_rank, k, n, int(oa[-1]), nq, int(qoa[-1])], dtype=np.uint64).tofile(f)
+        ca[:int(oa[-1])].astype(np.uint32).tofile(f); oa.tofile(f); qa[:int(qoa[-1])].astype(np.uint32).tofile(f); qoa.tofile(f)
+        np.array([int(ob[-1]), int(qob[-1])], dtype=np.uint64).tofile(f)
+        cb[:int(ob[-1])].astype(np.uint32).tofile(f); ob.tofile(f); qb[:int(qob[-1])].astype(np.uint32).tofile(f); qob.tofile(f)
+        np.ascontiguousarray(tab, dtype=np.uint16).tofile(f)
+    e = dict(os.environ); e["ASAN_OPTIONS"] = "detect_leaks=0"
+    r = subprocess.run([runner, case, out], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+    raw = np.fromfile(out, dtype=np.uint8)
+    idx = raw[:nq * k * 8].view(np.uint64).reshape(nq, k)
+    rank = raw[nq * k * 8:nq * k * 12].view(np.int32).reshape(nq, k)
+    cnt = raw[nq * k * 12:].view(np.uint32)
+    return idx, rank, cnt
+
+
+def test_weighted_pair_topk(oracle, runner, tmp_path):
+    """fz_query_topk_pair + rank table against the reference's weighted loop (app.py:995-1002)."""
+    from tts_amd.preprocess import full_process
+    from tts_amd.weighted_search import rank_table
+    cps, offs = synth.make_corpus(420, max_chars=40, seed=41, vocab_size=25)
+    keys = list(dict.fromkeys(synth.to_strings(cps, offs) + ["coke 1x24 (np)", "coke-zero 330ml", "a&b"]))
+    queries = synth.make_queries(cps, offs, 4, seed=42, max_chars=40) + ["coke zero", keys[3][:5], "zz"]
+    for thr, k in ((0.70, 10), (0.30, 7), (0.0, 300)):
+        tab, vals, min_rank = rank_table(thr)
+        idx, rank, cnt = _run_pair(runner, tmp_path, keys, [full_process(s) for s in keys], queries,
+                                   [full_process(q) for q in queries], tab, min_rank, k)
+        for qi, q in enumerate(queries):
+            exp = [(i, oracle.weighted_score(q, s)) for i, s in enumerate(keys)]
+            exp = [(i, v) for i, v in exp if v >= thr and q != keys[i]]
+            exp.sort(key=lambda x: x[1], reverse=True)
+            got = [(int(idx[qi, j]), vals[int(rank[qi, j]) - 1]) for j in range(int(cnt[qi]))]
+            got = [(i, v) for i, v in got]
+            exp_k = [(i, v) for i, v in [(i, oracle.weighted_score(q, s)) for i, s in enumerate(keys)] if v >= thr]
+            exp_k.sort(key=lambda x: x[1], reverse=True)
+            # the device scores a key equal to the query like any other (the host class special-cases it)
+            if q not in keys:
+                assert got == exp_k[:k], (thr, k, q, got[:4], exp_k[:4])
+
+
+def test_first_passing_index(oracle, runner, tmp_path):
+    """FZ_ORDER_BY_INDEX: the first candidates in list order whose ratio passes (app.py:1009-1011)."""
+    cand = ["abcdefgh" * 13 + "x", "zzz", "abcdefgh" * 13 + "y", "abcdefgh" * 13, "abcdefgh" * 13 + "yy"] * 3
+    q = "abcdefgh" * 13 + "z"
+    idx, score, cnt = _run(runner, tmp_path, 2, 1 | 0x100, cand, [q, "nothing"], min_score=99, k=4)
+    exp = [i for i, s in enumerate(cand) if oracle.score(oracle.RATIO, q, s) >= 99][:4]
+    assert [int(idx[0, j]) for j in range(int(cnt[0]))] == exp and int(cnt[1]) == 0
+
+
+def test_weighted_pair_many_ties(oracle, runner, tmp_path):
+    """> SEL_TIECAP candidates with the same rank at the cut: the in-order walk of fz_select16_topk"""
+    from tts_amd.weighted_search import rank_table
+    keys = ["k%05d" % i for i in range(2600)] + ["zz top", "zz"]
+    tab, vals, min_rank = rank_table(0.0)
+    idx, rank, cnt = _run_pair(runner, tmp_path, keys, keys, ["zz", "qq"], ["zz", "qq"], tab, min_rank, 12)
+    for qi, q in enumerate(["zz", "qq"]):
+        exp = [(i, oracle.weighted_score(q, s)) for i, s in enumerate(keys) if q != s or True]
+        exp = [(i, min(v, 0.99) if q == keys[i] else v) for i, v in exp]
+        exp.sort(key=lambda x: x[1], reverse=True)
+        got = [(int(idx[qi, j]), vals[int(rank[qi, j]) - 1]) for j in range(int(cnt[qi]))]
+        assert got == exp[:12], (q, got, exp[:12])

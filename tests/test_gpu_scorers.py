@@ -165,3 +165,30 @@ def test_wide_alphabet_all_scorers(oracle):
         for qi in range(3):
             for i in range(0, len(cand), 37):
                 assert int(lev[qi, i]) == oracle.levenshtein(queries[qi], cand[i])
+
+
+def test_weighted_fuzzysearch_dropin(oracle):
+    """The reference's weighted FuzzySearch (app.py:949-1032) end to end: dict de-duplication,
+    exact-key and ratio>98 bypasses, 0.5*partial + 0.5*token_set capped at 0.99, top_n."""
+    from tts_amd.weighted_search import WeightedFuzzySearch
+    cps, offs = synth.make_corpus(3000, max_chars=40, seed=81, vocab_size=60)
+    base = synth.to_strings(cps, offs)
+    products = [s.upper() if i % 4 == 0 else s for i, s in enumerate(base)]
+    products += ["Coke 1×24 NP Sleek Can", "coke 1x24 np sleek can", "Sprite 330ml 1x24", "Sprite Zero", "", "  ",
+                 "Fanta Orange 1.5L (PET)", "fanta-orange 1.5l", "abcdefgh" * 13 + "x", "abcdefgh" * 13 + "y"]
+    customers = ["FATHIMA GROCERY", "Al Madina Supermarket", "fathima grocery llc", "Carrefour", "fathima grocery"]
+    fs = WeightedFuzzySearch(products, customers)
+    assert fs.products_normalized == {oracle.weighted_normalize_string(p): p for p in products}
+    queries = ["sprite 330ml", "coke 1×24 np sleek can", "COKE 1X24 NP SLEEK CAN", "fanta orange", "sprit zero", "",
+               "abcdefgh" * 13 + "z", "zzzz", base[5], base[9][:6], base[11] + " xx"] + synth.make_queries(cps, offs, 6, seed=82, max_chars=40)
+    for q in queries:
+        got = fs.find_best_matches(q, "product")
+        exp = oracle.weighted_find_best_matches(products, q)
+        assert got == exp, (q, got[:3], exp[:3])
+    for q in ("fatima grocery", "fathima grocery", "madina", "carrefour express"):
+        assert fs.find_best_matches(q, "customer") == oracle.weighted_find_best_matches(customers, q), q
+    fs.close()
+    lo = WeightedFuzzySearch(products, customers, threshold=0.30, top_n=25)
+    for q in queries[:6]:
+        assert lo.find_best_matches(q, "product") == oracle.weighted_find_best_matches(products, q, 0.30, 0.98, 25), q
+    lo.close()

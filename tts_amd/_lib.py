@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("FUZZYHIP_LIB") or os.path.join(_HERE, "libfuzzyhip.so
 TOKEN_SET, RATIO, TOKEN_SORT, PARTIAL, LEVENSHTEIN = 0, 1, 2, 3, 4
 SCORERS = {"token_set": TOKEN_SET, "ratio": RATIO, "token_sort": TOKEN_SORT, "partial": PARTIAL,
            "levenshtein": LEVENSHTEIN}
+ORDER_BY_INDEX = 0x100
 MAX_K = 1024
 IDX_BITS = 40
 IDX_MASK = (1 << IDX_BITS) - 1
@@ -53,6 +54,10 @@ _SIGNATURES = {
     "fz_query_topk_keys": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int,
                                           ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int]),
+    "fz_query_topk_pair": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_u32p, c_u64p,
+                                          ctypes.c_void_p, ctypes.c_int, c_u32p, c_u64p, ctypes.c_uint32,
+                                          ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint32, ctypes.c_uint32,
+                                          c_u64p, c_i32p, c_u32p]),
     "fz_merge_topk": (ctypes.c_int, [c_u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_u64p,
                                      c_i32p, c_u32p]),
     "fz_score_all": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int, c_u8p]),

@@ -116,4 +116,31 @@ struct FzSelectParams {
     uint64_t base_index;
     uint64_t *out_keys;       // [rows][k]
     uint32_t *out_cnt;        // [rows] or null
+    uint32_t flat;            // 1: every passing score counts as min_score, so the order is by index only
+};
+
+// ---- two scorers combined through a rank table (fz_query_topk_pair) ------------------------------
+#define FZ_RANK_DIM 101u          // scores 0..100 on both axes
+
+struct FzCombineParams {
+    const uint8_t *scores_a;      // [rows][stride_a], physical order of view a
+    const uint8_t *scores_b;
+    uint64_t stride_a, stride_b;
+    const uint32_t *phys_a;       // [n] original index -> physical position in view a
+    const uint32_t *phys_b;
+    const uint16_t *rank_tab;     // [101*101] rank of the pair (a, b); larger = better
+    uint16_t *ranks;              // out [rows][stride_r], ORIGINAL candidate order
+    uint64_t stride_r;
+    uint32_t n;
+};
+
+struct FzSelect16Params {
+    const uint16_t *ranks;        // [rows][stride_r], original order
+    uint64_t stride_r;
+    uint32_t n;
+    uint32_t min_rank;            // keep rank >= min_rank
+    uint32_t k;
+    uint64_t base_index;
+    uint64_t *out_keys;           // [rows][k]: (rank << 40) | (2^40-1 - global index), 0 = padding
+    uint32_t *out_cnt;
 };

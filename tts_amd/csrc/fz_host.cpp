@@ -29,6 +29,8 @@ hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq,
 hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st);
 size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves);
 hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_t st);
+hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_t st);
+hipError_t fz_launch_select16(const FzSelect16Params &p, uint32_t rows, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -138,6 +140,8 @@ struct fz_corpus {
     uint64_t *d_keys = nullptr; size_t keys_cap = 0;
     uint32_t *d_cnt = nullptr; size_t cnt_cap = 0;
     uint8_t *d_score_tab[2] = {nullptr, nullptr};         // stream kernel: T[L][d] per rounding form
+    uint16_t *d_ranks = nullptr; size_t ranks_cap = 0;    // fz_query_topk_pair: combined ranks, rank table
+    uint16_t *d_rank_tab = nullptr; size_t rank_tab_cap = 0;
     bool use_stream = true;                               // FUZZYHIP_NO_STREAM=1 forces the general kernel
     uint32_t stream_waves = 16, stream_blocks = 8192;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
     std::vector<hipEvent_t> events;
@@ -235,7 +239,7 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (View &v : c->views) free_view(v);
     for (void *p : {(void *)c->d_scores, (void *)c->d_qbuf, (void *)c->d_keys, (void *)c->d_cnt,
-                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1]})
+                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1], (void *)c->d_ranks, (void *)c->d_rank_tab})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -695,6 +699,7 @@ enum RunMode { RUN_TOPK_HOST, RUN_TOPK_DEVICE, RUN_SCORE_ALL, RUN_DIST_ALL };
 struct RunOut {
     uint64_t *idx = nullptr; int32_t *score = nullptr; uint32_t *cnt = nullptr;     // TOPK_HOST
     uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr; int sync = 1;           // TOPK_DEVICE
+    uint32_t flat = 0;                         // FZ_ORDER_BY_INDEX: every passing candidate ties
     uint8_t *scores = nullptr;                                                      // SCORE_ALL
     uint16_t *dists = nullptr;                                                      // DIST_ALL
 };
@@ -730,6 +735,130 @@ static int scorer_plan(int scorer, int *view, int *mode, FzTies *ties)
     default:
         return fail(FZ_ERR_INVALID, "scorer %d is not implemented by this build", scorer);
     }
+}
+
+// Scores `rows` queries (q0 .. q0+rows) of one view into c->d_scores, rows [0, rows): builds the
+// query tables on the host, uploads them, launches the scoring kernels on `st`.  `ev_begin`, when
+// given, is recorded between the upload and the first launch.
+static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const uint32_t *q_cps,
+                      const uint64_t *q_offs, uint64_t q0, uint32_t rows, uint64_t row_stride,
+                      hipStream_t st, hipEvent_t ev_begin)
+{
+    const View &v = c->views[view_kind];
+    int rc;
+    std::vector<Tok> toks;
+    auto t0 = std::chrono::steady_clock::now();
+    QueryBatch b;
+    const bool stream_mode = kmode == FZ_MODE_TOKEN_SET || kmode == FZ_MODE_RATIO;
+    b.allow_stream = c->use_stream && stream_mode && (v.n_s1 + v.n_s2) > 0 && row_stride <= 0xFFFFFFFFull;
+    // the score table covers L < 128; a stream tile holds at most 64 symbols.  token_set looks up
+    // L = m + clen - 2, ratio L = m + clen.
+    b.stream_max_m = kmode == FZ_MODE_TOKEN_SET ? (FZ_STREAM_TAB + 1u - 64u) : (FZ_STREAM_TAB - 1u - 64u);
+    for (uint32_t r = 0; r < rows; ++r) {
+        const uint64_t qi = q0 + r;
+        if (q_offs[qi + 1] < q_offs[qi]) return fail(FZ_ERR_INVALID, "query offsets not monotone at %llu", (unsigned long long)qi);
+        rc = prepare_query(c, view_kind, q_cps + q_offs[qi], q_offs[qi + 1] - q_offs[qi], r, b, toks);
+        if (rc != FZ_OK) return rc;
+    }
+    b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches two records ahead
+    b.recs.push_back(FzRec{0, 0, 0, 0});
+    // one device blob: [FzQuery list][peq][tok_id][tok_pos][tok_len1][stream records][qrec][rows]
+    struct Launch { int W; uint32_t first, count; bool slow_only; };
+    std::vector<FzQuery> qlist;
+    std::vector<Launch> launches;
+    for (int pass = 0; pass < 2; ++pass)
+        for (auto &kv : (pass == 0 ? b.classes : b.slow_classes)) {
+            launches.push_back({kv.first, (uint32_t)qlist.size(), (uint32_t)kv.second.size(), pass == 1});
+            qlist.insert(qlist.end(), kv.second.begin(), kv.second.end());
+        }
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_q = 0, o_peq = align16(o_q + qlist.size() * sizeof(FzQuery));
+    const size_t o_id = o_peq + b.peq.size() * 4, o_pos = o_id + b.tok_id.size() * 4;
+    const size_t o_len = o_pos + b.tok_pos.size() * 4;
+    const size_t o_rec = align16(o_len + b.tok_len1.size() * 4);
+    const size_t o_qrec = o_rec + b.recs.size() * sizeof(FzRec);
+    const size_t o_rows = align16(o_qrec + b.qrec.size() * 4);
+    const size_t total = o_rows + 256;
+    std::vector<uint8_t> blob(total);
+    if (!qlist.empty()) memcpy(blob.data() + o_q, qlist.data(), qlist.size() * sizeof(FzQuery));
+    if (!b.peq.empty()) memcpy(blob.data() + o_peq, b.peq.data(), b.peq.size() * 4);
+    if (!b.tok_id.empty()) {
+        memcpy(blob.data() + o_id, b.tok_id.data(), b.tok_id.size() * 4);
+        memcpy(blob.data() + o_pos, b.tok_pos.data(), b.tok_pos.size() * 4);
+        memcpy(blob.data() + o_len, b.tok_len1.data(), b.tok_len1.size() * 4);
+    }
+    memcpy(blob.data() + o_rec, b.recs.data(), b.recs.size() * sizeof(FzRec));
+    if (!b.qrec.empty()) memcpy(blob.data() + o_qrec, b.qrec.data(), b.qrec.size() * 4);
+    memcpy(blob.data() + o_rows, b.row_of_sym, 256);
+    c->timing.host_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if ((rc = ensure(&c->d_qbuf, &c->qbuf_cap, blob.size())) != FZ_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_qbuf, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));          // blob is pageable host memory owned by this scope
+
+    if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, st));
+    for (auto &l : launches) {
+        const int W = l.W;
+        const uint32_t first = l.first, count = l.count;
+        FzScoreParams p{};
+        p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
+        p.ntiles = l.slow_only ? v.n_slow : v.ntiles;
+        p.tile_list = l.slow_only ? v.d_tiles_slow : nullptr;
+        p.alphabet = v.alphabet;
+        p.wide = v.wide ? 1u : 0u;
+        uint32_t pmax = 1, peq_rows = 1;
+        for (uint32_t i = 0; i < count; ++i) {
+            pmax = std::max(pmax, qlist[first + i].n_ids);
+            peq_rows = std::max(peq_rows, qlist[first + i].peq_rows);
+        }
+        p.pmax = pmax;
+        p.peq_rows = peq_rows;
+        const uint32_t tkd = v.wide ? 16u : 8u;             // symbol dwords per text keep-mask word
+        p.ntkw = std::max<uint32_t>(1, (v.max_ndw + tkd - 1) / tkd);
+        p.nwaves = 4;
+        while (p.nwaves > 1 && fz_score_lds_bytes(W, p) > 64 * 1024) p.nwaves >>= 1;
+        if (fz_score_lds_bytes(W, p) > 160 * 1024)
+            return fail(FZ_ERR_TOO_LONG, "pattern width %d words x candidate length %u does not fit in LDS", W, v.max_len);
+        uint64_t work = (uint64_t)p.ntiles * count;
+        uint32_t tpb = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(p.nwaves, work / 8192));
+        tpb = (tpb + p.nwaves - 1) / p.nwaves * p.nwaves;
+        p.tiles_per_block = tpb;
+        p.queries = reinterpret_cast<const FzQuery *>(c->d_qbuf + o_q) + first;
+        p.qblob = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_peq);
+        p.qtok_id = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_id);
+        p.qtok_pos = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_pos);
+        p.qtok_len1 = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_len);
+        p.scores = c->d_scores; p.row_stride = row_stride;
+        p.ties = ties;
+        HIP_TRY(fz_launch_score(W, kmode, p, count, st));
+        c->timing.score_launches++;
+    }
+    if (!b.qrec.empty()) {
+        const uint32_t stride = b.nrows <= 41u ? 41u : 65u;
+        for (int W = 1; W <= 2; ++W) {
+            const uint32_t nt = W == 1 ? v.n_s1 : v.n_s2;
+            if (nt == 0) continue;
+            FzStreamParams p{};
+            p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
+            p.tile_list = W == 1 ? v.d_tiles_s1 : v.d_tiles_s2;
+            p.ntiles = nt; p.stride = stride;
+            p.nwaves = 16;
+            while (p.nwaves > 1 && fz_stream_lds_bytes(W, (int)stride, p.nwaves) > 160 * 1024) --p.nwaves;
+            p.nwaves = std::min<uint32_t>(p.nwaves, std::max<uint32_t>(1, c->stream_waves));
+            p.nq = (uint32_t)b.qrec.size();
+            // enough blocks to balance the chip, enough queries per block to amortise the tile set-up
+            const uint64_t bx = (nt + p.nwaves - 1) / p.nwaves;
+            uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (c->stream_blocks + bx - 1) / bx));
+            p.q_per_block = (uint32_t)((p.nq + by - 1) / by);
+            p.row_of_sym = c->d_qbuf + o_rows;
+            p.recs = reinterpret_cast<const FzRec *>(c->d_qbuf + o_rec);
+            p.qrec = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_qrec);
+            p.score_tab = c->d_score_tab[kmode == FZ_MODE_TOKEN_SET ? 0 : 1];
+            p.scores = c->d_scores; p.row_stride = (uint32_t)row_stride;
+            HIP_TRY(fz_launch_stream(W, kmode, p, st));
+            c->timing.score_launches++;
+        }
+    }
+    return FZ_OK;
 }
 
 static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
@@ -787,119 +916,9 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
 
     for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk) {
         const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, nq - q0);
-        auto t0 = std::chrono::steady_clock::now();
-        QueryBatch b;
-        const bool stream_mode = kmode == FZ_MODE_TOKEN_SET || kmode == FZ_MODE_RATIO;
-        b.allow_stream = c->use_stream && stream_mode && (v.n_s1 + v.n_s2) > 0 && row_stride <= 0xFFFFFFFFull;
-        // the score table covers L < 128; a stream tile holds at most 64 symbols.  token_set looks up
-        // L = m + clen - 2, ratio L = m + clen.
-        b.stream_max_m = kmode == FZ_MODE_TOKEN_SET ? (FZ_STREAM_TAB + 1u - 64u) : (FZ_STREAM_TAB - 1u - 64u);
-        for (uint32_t r = 0; r < rows; ++r) {
-            const uint64_t qi = q0 + r;
-            if (q_offs[qi + 1] < q_offs[qi]) return fail(FZ_ERR_INVALID, "query offsets not monotone at %llu", (unsigned long long)qi);
-            rc = prepare_query(c, view_kind, q_cps + q_offs[qi], q_offs[qi + 1] - q_offs[qi], r, b, toks);
-            if (rc != FZ_OK) return rc;
-        }
-        b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches two records ahead
-        b.recs.push_back(FzRec{0, 0, 0, 0});
-        // one device blob: [FzQuery list][peq][tok_id][tok_pos][tok_len1][stream records][qrec][rows]
-        struct Launch { int W; uint32_t first, count; bool slow_only; };
-        std::vector<FzQuery> qlist;
-        std::vector<Launch> launches;
-        for (int pass = 0; pass < 2; ++pass)
-            for (auto &kv : (pass == 0 ? b.classes : b.slow_classes)) {
-                launches.push_back({kv.first, (uint32_t)qlist.size(), (uint32_t)kv.second.size(), pass == 1});
-                qlist.insert(qlist.end(), kv.second.begin(), kv.second.end());
-            }
-        auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-        const size_t o_q = 0, o_peq = align16(o_q + qlist.size() * sizeof(FzQuery));
-        const size_t o_id = o_peq + b.peq.size() * 4, o_pos = o_id + b.tok_id.size() * 4;
-        const size_t o_len = o_pos + b.tok_pos.size() * 4;
-        const size_t o_rec = align16(o_len + b.tok_len1.size() * 4);
-        const size_t o_qrec = o_rec + b.recs.size() * sizeof(FzRec);
-        const size_t o_rows = align16(o_qrec + b.qrec.size() * 4);
-        const size_t total = o_rows + 256;
-        std::vector<uint8_t> blob(total);
-        if (!qlist.empty()) memcpy(blob.data() + o_q, qlist.data(), qlist.size() * sizeof(FzQuery));
-        if (!b.peq.empty()) memcpy(blob.data() + o_peq, b.peq.data(), b.peq.size() * 4);
-        if (!b.tok_id.empty()) {
-            memcpy(blob.data() + o_id, b.tok_id.data(), b.tok_id.size() * 4);
-            memcpy(blob.data() + o_pos, b.tok_pos.data(), b.tok_pos.size() * 4);
-            memcpy(blob.data() + o_len, b.tok_len1.data(), b.tok_len1.size() * 4);
-        }
-        memcpy(blob.data() + o_rec, b.recs.data(), b.recs.size() * sizeof(FzRec));
-        if (!b.qrec.empty()) memcpy(blob.data() + o_qrec, b.qrec.data(), b.qrec.size() * 4);
-        memcpy(blob.data() + o_rows, b.row_of_sym, 256);
-        c->timing.host_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if ((rc = ensure(&c->d_qbuf, &c->qbuf_cap, blob.size())) != FZ_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(c->d_qbuf, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));          // blob is pageable host memory owned by this scope
-
         hipEvent_t e0 = get_event(c, ev++), e1 = get_event(c, ev++);
         if (!e0 || !e1) return fail(FZ_ERR_HIP, "hipEventCreate failed");
-        HIP_TRY(hipEventRecord(e0, st));
-        for (auto &l : launches) {
-            const int W = l.W;
-            const uint32_t first = l.first, count = l.count;
-            FzScoreParams p{};
-            p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
-            p.ntiles = l.slow_only ? v.n_slow : v.ntiles;
-            p.tile_list = l.slow_only ? v.d_tiles_slow : nullptr;
-            p.alphabet = v.alphabet;
-            p.wide = v.wide ? 1u : 0u;
-            uint32_t pmax = 1, peq_rows = 1;
-            for (uint32_t i = 0; i < count; ++i) {
-                pmax = std::max(pmax, qlist[first + i].n_ids);
-                peq_rows = std::max(peq_rows, qlist[first + i].peq_rows);
-            }
-            p.pmax = pmax;
-            p.peq_rows = peq_rows;
-            const uint32_t tkd = v.wide ? 16u : 8u;             // symbol dwords per text keep-mask word
-            p.ntkw = std::max<uint32_t>(1, (v.max_ndw + tkd - 1) / tkd);
-            p.nwaves = 4;
-            while (p.nwaves > 1 && fz_score_lds_bytes(W, p) > 64 * 1024) p.nwaves >>= 1;
-            if (fz_score_lds_bytes(W, p) > 160 * 1024)
-                return fail(FZ_ERR_TOO_LONG, "pattern width %d words x candidate length %u does not fit in LDS", W, v.max_len);
-            uint64_t work = (uint64_t)p.ntiles * count;
-            uint32_t tpb = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(p.nwaves, work / 8192));
-            tpb = (tpb + p.nwaves - 1) / p.nwaves * p.nwaves;
-            p.tiles_per_block = tpb;
-            p.queries = reinterpret_cast<const FzQuery *>(c->d_qbuf + o_q) + first;
-            p.qblob = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_peq);
-            p.qtok_id = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_id);
-            p.qtok_pos = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_pos);
-            p.qtok_len1 = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_len);
-            p.scores = c->d_scores; p.row_stride = row_stride;
-            p.ties = ties;
-            HIP_TRY(fz_launch_score(W, kmode, p, count, st));
-            c->timing.score_launches++;
-        }
-        if (!b.qrec.empty()) {
-            const uint32_t stride = b.nrows <= 41u ? 41u : 65u;
-            for (int W = 1; W <= 2; ++W) {
-                const uint32_t nt = W == 1 ? v.n_s1 : v.n_s2;
-                if (nt == 0) continue;
-                FzStreamParams p{};
-                p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
-                p.tile_list = W == 1 ? v.d_tiles_s1 : v.d_tiles_s2;
-                p.ntiles = nt; p.stride = stride;
-                p.nwaves = 16;
-                while (p.nwaves > 1 && fz_stream_lds_bytes(W, (int)stride, p.nwaves) > 160 * 1024) --p.nwaves;
-                p.nwaves = std::min<uint32_t>(p.nwaves, std::max<uint32_t>(1, c->stream_waves));
-                p.nq = (uint32_t)b.qrec.size();
-                // enough blocks to balance the chip, enough queries per block to amortise the tile set-up
-                const uint64_t bx = (nt + p.nwaves - 1) / p.nwaves;
-                uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (c->stream_blocks + bx - 1) / bx));
-                p.q_per_block = (uint32_t)((p.nq + by - 1) / by);
-                p.row_of_sym = c->d_qbuf + o_rows;
-                p.recs = reinterpret_cast<const FzRec *>(c->d_qbuf + o_rec);
-                p.qrec = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_qrec);
-                p.score_tab = c->d_score_tab[kmode == FZ_MODE_TOKEN_SET ? 0 : 1];
-                p.scores = c->d_scores; p.row_stride = (uint32_t)row_stride;
-                HIP_TRY(fz_launch_stream(W, kmode, p, st));
-                c->timing.score_launches++;
-            }
-        }
+        if ((rc = score_rows(c, view_kind, kmode, ties, q_cps, q_offs, q0, rows, row_stride, st, e0)) != FZ_OK) return rc;
         HIP_TRY(hipEventRecord(e1, st));
         score_spans.push_back({ev - 2, ev - 1});
         c->timing.pairs += (uint64_t)rows * c->n;
@@ -910,6 +929,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             sp.orig_of_phys = v.d_orig_of_phys; sp.phys_of_orig = v.d_phys_of_orig;
             sp.min_score = min_score; sp.k = k; sp.base_index = c->base;
             sp.out_keys = d_keys + q0 * k; sp.out_cnt = d_cnt ? d_cnt + q0 : nullptr;
+            sp.flat = o.flat;
             HIP_TRY(fz_launch_select(sp, rows, st));
             c->timing.select_launches++;
             hipEvent_t e2 = get_event(c, ev++);
@@ -960,8 +980,9 @@ extern "C" int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t
 {
     if (nq && k && (!out_idx || !out_score)) return fail(FZ_ERR_INVALID, "null output buffers");
     int view, kmode; FzTies ties; int rc;
-    if ((rc = scorer_plan(scorer, &view, &kmode, &ties)) != FZ_OK) return rc;
+    if ((rc = scorer_plan(scorer & 0xFF, &view, &kmode, &ties)) != FZ_OK) return rc;
     RunOut o; o.idx = out_idx; o.score = out_score; o.cnt = out_cnt;
+    o.flat = (scorer & FZ_ORDER_BY_INDEX) ? 1u : 0u;
     return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_HOST, o);
 }
 
@@ -971,8 +992,9 @@ extern "C" int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uin
 {
     if (nq && k && !out_keys_device) return fail(FZ_ERR_INVALID, "null device key buffer");
     int view, kmode; FzTies ties; int rc;
-    if ((rc = scorer_plan(scorer, &view, &kmode, &ties)) != FZ_OK) return rc;
+    if ((rc = scorer_plan(scorer & 0xFF, &view, &kmode, &ties)) != FZ_OK) return rc;
     RunOut o; o.d_keys = out_keys_device; o.d_cnt = out_cnt_device; o.sync = sync;
+    o.flat = (scorer & FZ_ORDER_BY_INDEX) ? 1u : 0u;
     return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_DEVICE, o);
 }
 
@@ -994,6 +1016,73 @@ extern "C" int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64
     RunOut o; o.dists = out_dist;
     return run_queries(c, q_cps, q_offs, nq, VIEW_RAW, kind == 0 ? FZ_MODE_INDEL : FZ_MODE_LEV,
                        FzTies{0, 0}, 0, 0, RUN_DIST_ALL, o);
+}
+
+// Two scorers over two corpora that hold the SAME candidate list in two string forms (e.g. the
+// normalised strings for partial_ratio and their full_process-ed forms for token_set_ratio),
+// combined per candidate through the caller's 101 x 101 rank table, then top-k on the rank.
+extern "C" int fz_query_topk_pair(fz_corpus *ca, int scorer_a, const uint32_t *qa_cps, const uint64_t *qa_offs,
+                                  fz_corpus *cb, int scorer_b, const uint32_t *qb_cps, const uint64_t *qb_offs,
+                                  uint32_t nq, const uint16_t *rank_tab, uint32_t min_rank, uint32_t k,
+                                  uint64_t *out_idx, int32_t *out_rank, uint32_t *out_cnt)
+{
+    if (!ca || !cb || ca == cb) return fail(FZ_ERR_INVALID, "two distinct corpora are required");
+    if (ca->n != cb->n || ca->device != cb->device || ca->base != cb->base)
+        return fail(FZ_ERR_INVALID, "the two corpora must hold the same candidates (n, base index) on one device");
+    if (k > FZ_MAX_K) return fail(FZ_ERR_LIMIT, "k=%u exceeds FZ_MAX_K=%u", k, FZ_MAX_K);
+    if (nq && (!qa_offs || !qb_offs || !rank_tab)) return fail(FZ_ERR_INVALID, "null argument");
+    if (nq && k && (!out_idx || !out_rank)) return fail(FZ_ERR_INVALID, "null output buffers");
+    if (min_rank > 0xFFFFu) min_rank = 0x10000u;             // nothing can pass
+    int va, ma, vb, mb, rc; FzTies ta, tb;
+    if ((rc = scorer_plan(scorer_a, &va, &ma, &ta)) != FZ_OK) return rc;
+    if ((rc = scorer_plan(scorer_b, &vb, &mb, &tb)) != FZ_OK) return rc;
+    if (nq == 0) return FZ_OK;
+    if (out_cnt) memset(out_cnt, 0, (size_t)nq * 4);
+    if (k) { memset(out_idx, 0, (size_t)nq * k * 8); memset(out_rank, 0, (size_t)nq * k * 4); }
+    if (k == 0 || ca->n == 0 || min_rank > 0xFFFFu) return FZ_OK;
+
+    // lock both, lowest address first
+    fz_corpus *l1 = ca < cb ? ca : cb, *l2 = ca < cb ? cb : ca;
+    std::lock_guard<std::mutex> lk1(l1->mu);
+    std::lock_guard<std::mutex> lk2(l2->mu);
+    HIP_TRY(hipSetDevice(ca->device));
+    if ((rc = build_view(ca, va)) != FZ_OK) return rc;
+    if ((rc = build_view(cb, vb)) != FZ_OK) return rc;
+    const View &A = ca->views[va], &B = cb->views[vb];
+    hipStream_t st = ca->stream;
+    const uint64_t n = ca->n, stride_r = (n + 7) & ~7ull;
+    uint64_t rows_per_chunk = std::max<uint64_t>(1, ca->ws_limit / (std::max<uint64_t>(A.npad, B.npad) + 2 * stride_r));
+    rows_per_chunk = std::min<uint64_t>(rows_per_chunk, nq);
+    if ((rc = ensure(&ca->d_scores, &ca->scores_cap, (size_t)(rows_per_chunk * A.npad))) != FZ_OK) return rc;
+    if ((rc = ensure(&cb->d_scores, &cb->scores_cap, (size_t)(rows_per_chunk * B.npad))) != FZ_OK) return rc;
+    if ((rc = ensure(&ca->d_ranks, &ca->ranks_cap, (size_t)(rows_per_chunk * stride_r * 2))) != FZ_OK) return rc;
+    if ((rc = ensure(&ca->d_rank_tab, &ca->rank_tab_cap, (size_t)FZ_RANK_DIM * FZ_RANK_DIM * 2)) != FZ_OK) return rc;
+    if ((rc = ensure(&ca->d_keys, &ca->keys_cap, (size_t)nq * k * 8)) != FZ_OK) return rc;
+    if ((rc = ensure(&ca->d_cnt, &ca->cnt_cap, (size_t)nq * 4)) != FZ_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(ca->d_rank_tab, rank_tab, (size_t)FZ_RANK_DIM * FZ_RANK_DIM * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));                       // rank_tab is the caller's pageable memory
+    ca->timing = fz_timing{};
+    cb->timing = fz_timing{};
+    for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk) {
+        const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, nq - q0);
+        if ((rc = score_rows(ca, va, ma, ta, qa_cps, qa_offs, q0, rows, A.npad, st, nullptr)) != FZ_OK) return rc;
+        if ((rc = score_rows(cb, vb, mb, tb, qb_cps, qb_offs, q0, rows, B.npad, st, nullptr)) != FZ_OK) return rc;
+        FzCombineParams cp{};
+        cp.scores_a = ca->d_scores; cp.scores_b = cb->d_scores; cp.stride_a = A.npad; cp.stride_b = B.npad;
+        cp.phys_a = A.d_phys_of_orig; cp.phys_b = B.d_phys_of_orig; cp.rank_tab = ca->d_rank_tab;
+        cp.ranks = ca->d_ranks; cp.stride_r = stride_r; cp.n = (uint32_t)n;
+        HIP_TRY(fz_launch_combine(cp, rows, st));
+        FzSelect16Params sp{};
+        sp.ranks = ca->d_ranks; sp.stride_r = stride_r; sp.n = (uint32_t)n; sp.min_rank = min_rank; sp.k = k;
+        sp.base_index = ca->base; sp.out_keys = ca->d_keys + q0 * k; sp.out_cnt = ca->d_cnt + q0;
+        HIP_TRY(fz_launch_select16(sp, rows, st));
+        ca->timing.pairs += 2ull * rows * n;
+    }
+    std::vector<uint64_t> h_keys((size_t)nq * k);
+    HIP_TRY(hipMemcpyAsync(h_keys.data(), ca->d_keys, h_keys.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    decode_keys(h_keys.data(), nq, k, out_idx, out_rank, out_cnt);
+    return FZ_OK;
 }
 
 // Deterministic merge of per-shard key lists: plain descending sort of the n_lists*k keys of each

@@ -762,7 +762,8 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
             for (int a = 0; a < 4; ++a) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;       // a byte > 100 is not a score: skipped
+                    uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;             // a byte > 100 is not a score: skipped
+                    if (p.flat && s >= min_score) s = s <= 100u ? min_score : s;   // index order only
                     if (s >= tlow && s <= 100u && base + (uint32_t)(4 * a + b) < n) atomicAdd(&s_hist[s], 1u);
                 }
             }
@@ -788,7 +789,8 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
             for (int a = 0; a < 4; ++a) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;
+                    uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;
+                    if (p.flat && s >= min_score) s = s <= 100u ? min_score : s;
                     const uint32_t ph = base + (uint32_t)(4 * a + b);
                     if (ph < n && s >= sstar && s <= 100u) {
                         if (s > sstar) {
@@ -821,7 +823,10 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
             for (uint32_t o0 = 0u; o0 < n && found < need; o0 += SEL_THREADS) {
                 const uint32_t o = o0 + tid;
                 bool pred = false;
-                if (o < n) pred = (sc[p.phys_of_orig[o]] == (uint8_t)sstar);
+                if (o < n) {
+                    const uint32_t s = sc[p.phys_of_orig[o]];
+                    pred = p.flat ? (s >= sstar && s <= 100u) : (s == sstar);    // flat: sstar == min_score
+                }
                 const uint64_t bal = __ballot(pred);
                 if (lane == 0u) s_misc[4 + wave] = (uint32_t)__popcll(bal);
                 __syncthreads();
@@ -854,6 +859,159 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
         p.out_keys[(uint64_t)row * k + i] = out;
     }
     if (p.out_cnt != nullptr && tid == 0u) p.out_cnt[row] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// two scorers -> one rank per candidate -> top-k  (weighted FuzzySearch of reference app.py:995-1032)
+// ---------------------------------------------------------------------------------------------
+// The reference's weighted score is an fp64 expression of two integer scores; the host evaluates it
+// for all 101 x 101 pairs with the reference's own arithmetic and hands over the RANK of each value
+// among the distinct results, so ordering and threshold on the device are integer-exact.
+__global__ __launch_bounds__(256) void fz_combine_rank(FzCombineParams p)
+{
+    __shared__ uint16_t s_tab[FZ_RANK_DIM * FZ_RANK_DIM];
+    for (uint32_t i = threadIdx.x; i < FZ_RANK_DIM * FZ_RANK_DIM; i += blockDim.x) s_tab[i] = p.rank_tab[i];
+    __syncthreads();
+    const uint32_t row = blockIdx.y;
+    const uint8_t *sa = p.scores_a + (uint64_t)row * p.stride_a;
+    const uint8_t *sb = p.scores_b + (uint64_t)row * p.stride_b;
+    uint16_t *out = p.ranks + (uint64_t)row * p.stride_r;
+    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < p.n; o += gridDim.x * blockDim.x) {
+        uint32_t a = sa[p.phys_a[o]], b = sb[p.phys_b[o]];
+        if (a > 100u) a = 100u;
+        if (b > 100u) b = 100u;
+        out[o] = s_tab[a * FZ_RANK_DIM + b];
+    }
+}
+
+// suffix sums of a 256-bin histogram: s_cum[t] = #values in bins >= t, s_cum[256] = 0
+__device__ __forceinline__ void fz_sel16_suffix(const uint32_t *s_hist, uint32_t *s_cum, uint32_t *s_part)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __syncthreads();
+    uint32_t v = s_hist[tid];
+    for (uint32_t off = 1u; off < 64u; off <<= 1) {
+        const uint32_t t = __shfl_down(v, off, 64);
+        if (lane + off < 64u) v += t;
+    }
+    if (lane == 0u) s_part[wave] = v;
+    __syncthreads();
+    for (uint32_t w = wave + 1u; w < 4u; ++w) v += s_part[w];
+    s_cum[tid] = v;
+    if (tid == 0u) s_cum[256] = 0u;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void fz_select16_topk(FzSelect16Params p)
+{
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_cum[257];
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_misc[8];          // 0: hi bin  1: r*  2: n_gt  3: n_tie  4..7: wave counts
+    __shared__ uint64_t s_keys[FZ_MAX_K];
+    __shared__ uint32_t s_ties[SEL_TIECAP];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n = p.n, k = p.k, minr = p.min_rank;
+    const uint16_t *rk = p.ranks + (uint64_t)blockIdx.x * p.stride_r;
+
+    // ---- pass 1: high bytes ------------------------------------------------------------------
+    s_hist[tid] = 0u;
+    if (tid == 0u) { s_misc[0] = minr >> 8; s_misc[1] = minr; s_misc[2] = 0u; s_misc[3] = 0u; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const uint32_t r = rk[i];
+        if (r >= minr) atomicAdd(&s_hist[r >> 8], 1u);
+    }
+    fz_sel16_suffix(s_hist, s_cum, s_part);
+    if (s_cum[tid] >= k && s_cum[tid + 1u] < k && tid > s_misc[0]) s_misc[0] = tid;   // at most one bin
+    __syncthreads();
+    const uint32_t B = s_misc[0];
+    const uint32_t above = s_cum[B + 1u];                    // values in higher bins: all are results
+    __syncthreads();
+
+    // ---- pass 2: low bytes inside bin B ------------------------------------------------------
+    s_hist[tid] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const uint32_t r = rk[i];
+        if (r >= minr && (r >> 8) == B) atomicAdd(&s_hist[r & 255u], 1u);
+    }
+    fz_sel16_suffix(s_hist, s_cum, s_part);
+    {
+        const uint32_t kk = k - above;                       // above < k by construction (or B is the floor)
+        const uint32_t r = (B << 8) | tid;
+        if (above < k && s_cum[tid] >= kk && s_cum[tid + 1u] < kk && r > s_misc[1]) s_misc[1] = r;
+    }
+    __syncthreads();
+    const uint32_t rstar = s_misc[1];                        // k-th best rank (or min_rank)
+    const uint32_t lo = rstar & 255u;
+    const uint32_t n_gt = above + ((rstar >> 8) == B ? s_cum[lo + 1u] : 0u);
+    const uint32_t c_eq = (rstar >> 8) == B ? s_hist[lo] : 0u;
+    uint32_t need = n_gt < k ? k - n_gt : 0u;
+    if (need > c_eq) need = c_eq;
+    const bool few_ties = c_eq <= SEL_TIECAP;
+    __syncthreads();
+
+    // ---- pass 3: collect ---------------------------------------------------------------------
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const uint32_t r = rk[i];
+        if (r > rstar) {
+            const uint32_t pos = atomicAdd(&s_misc[2], 1u);
+            if (pos < FZ_MAX_K) s_keys[pos] = ((uint64_t)r << 32) | (uint64_t)(0xFFFFFFFFu - i);
+        } else if (r == rstar && r >= minr && few_ties && need > 0u) {
+            const uint32_t pos = atomicAdd(&s_misc[3], 1u);
+            if (pos < SEL_TIECAP) s_ties[pos] = i;
+        }
+    }
+    __syncthreads();
+    if (need > 0u) {
+        if (few_ties) {
+            if (need < c_eq) {
+                uint32_t P = 2u;
+                while (P < c_eq) P <<= 1;
+                for (uint32_t i = c_eq + tid; i < P; i += blockDim.x) s_ties[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                fz_bitonic<uint32_t, false>(s_ties, P);
+            }
+        } else {
+            // many ties: candidates are in ORIGINAL order here, so the first `need` tied ones win
+            uint32_t found = 0u;
+            for (uint32_t o0 = 0u; o0 < n && found < need; o0 += SEL_THREADS) {
+                const uint32_t o = o0 + tid;
+                const bool pred = o < n && rk[o] == (uint16_t)rstar;
+                const uint64_t bal = __ballot(pred);
+                if (lane == 0u) s_misc[4 + wave] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                uint32_t before = found;
+                for (uint32_t w = 0; w < wave; ++w) before += s_misc[4 + w];
+                const uint32_t mine = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (pred && mine < need) s_ties[mine] = o;
+                found += s_misc[4] + s_misc[5] + s_misc[6] + s_misc[7];
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < need; i += blockDim.x)
+            s_keys[n_gt + i] = ((uint64_t)rstar << 32) | (uint64_t)(0xFFFFFFFFu - s_ties[i]);
+    }
+    const uint32_t total = n_gt + need;
+    uint32_t P = 2u;
+    while (P < total) P <<= 1;
+    __syncthreads();
+    for (uint32_t i = total + tid; i < P; i += blockDim.x) s_keys[i] = 0ull;
+    __syncthreads();
+    fz_bitonic<uint64_t, true>(s_keys, P);
+    for (uint32_t i = tid; i < k; i += blockDim.x) {
+        uint64_t out = 0ull;
+        if (i < total) {
+            const uint64_t key = s_keys[i];
+            const uint64_t gidx = p.base_index + (uint64_t)(0xFFFFFFFFu - (uint32_t)key);
+            out = ((key >> 32) << FZ_IDX_BITS) | (FZ_IDX_MASK - gidx);
+        }
+        p.out_keys[(uint64_t)blockIdx.x * k + i] = out;
+    }
+    if (p.out_cnt != nullptr && tid == 0u) p.out_cnt[blockIdx.x] = total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -949,5 +1107,20 @@ hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t 
 {
     if (rows == 0u || p.k == 0u) return hipSuccess;
     hipLaunchKernelGGL(fz_select_topk, dim3(rows), dim3(SEL_THREADS), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_t st)
+{
+    if (rows == 0u || p.n == 0u) return hipSuccess;
+    const uint32_t bx = (uint32_t)((p.n + 255u) / 256u);
+    hipLaunchKernelGGL(fz_combine_rank, dim3(bx < 2048u ? bx : 2048u, rows), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t fz_launch_select16(const FzSelect16Params &p, uint32_t rows, hipStream_t st)
+{
+    if (rows == 0u || p.k == 0u) return hipSuccess;
+    hipLaunchKernelGGL(fz_select16_topk, dim3(rows), dim3(SEL_THREADS), 0, st, p);
     return hipGetLastError();
 }
