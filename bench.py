@@ -70,9 +70,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--candidates", type=int, default=1_000_000, help="per GPU")
-    ap.add_argument("--queries", type=int, default=1000)
-    ap.add_argument("--max-chars", type=int, default=64)
+    ap.add_argument("--workload", choices=["C2", "C4"], default="C2",
+                    help="C2 (default, the metric's configuration): names <= 64 chars; C4: long strings "
+                         "64-512 chars (multi-word carry chain), an extra measurement, not the bench line")
+    ap.add_argument("--candidates", type=int, default=None, help="per GPU (default 1e6; C4: 2e5)")
+    ap.add_argument("--queries", type=int, default=None, help="default 1000; C4: 100")
+    ap.add_argument("--max-chars", type=int, default=None)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--threshold", type=float, default=0.35)
     ap.add_argument("--latency-reps", type=int, default=100)
@@ -83,6 +86,15 @@ def main():
     import torch.distributed as dist
     from tts_amd import Corpus, merge_topk, synth
     from tts_amd.preprocess import min_score_for_threshold
+
+    long_strings = args.workload == "C4"
+    if args.candidates is None:
+        args.candidates = 200_000 if long_strings else 1_000_000
+    if args.queries is None:
+        args.queries = 100 if long_strings else 1000
+    if args.max_chars is None:
+        args.max_chars = 512 if long_strings else 64
+    gen = dict(min_tokens=8, max_tokens=60) if long_strings else {}
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -96,12 +108,12 @@ def main():
 
     # this rank's shard: its own seeded corpus, global indices [rank*n, (rank+1)*n)
     n = args.candidates
-    cps, offs = synth.make_corpus(n, max_chars=args.max_chars, seed=synth.CORPUS_SEED + rank)
+    cps, offs = synth.make_corpus(n, max_chars=args.max_chars, seed=synth.CORPUS_SEED + rank, **gen)
     # the same queries on every rank, drawn from rank 0's shard
     if rank == 0:
         q_src = (cps, offs)
     else:
-        q_src = synth.make_corpus(n, max_chars=args.max_chars, seed=synth.CORPUS_SEED)
+        q_src = synth.make_corpus(n, max_chars=args.max_chars, seed=synth.CORPUS_SEED, **gen)
     queries = synth.make_queries(q_src[0], q_src[1], args.queries, seed=synth.QUERY_SEED,
                                  max_chars=args.max_chars)
     del q_src
@@ -168,8 +180,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"C2: {nq} queries x {n} candidates/GPU (<= {args.max_chars} chars, "
-                                   f"Zipf(1.2) tokens over 50k vocabulary), top-{k}, threshold {args.threshold}",
+            "config": {"workload": (f"C4: {nq} queries x {n} candidates/GPU (8-60 tokens, <= {args.max_chars} chars, "
+                                    f"multi-word patterns), top-{k}, threshold {args.threshold}") if long_strings else
+                                   (f"C2: {nq} queries x {n} candidates/GPU (<= {args.max_chars} chars, "
+                                    f"Zipf(1.2) tokens over 50k vocabulary), top-{k}, threshold {args.threshold}"),
                        "queries": nq, "candidates_per_gpu": n, "k": k, "min_score": min_score,
                        "parallelism": f"shard{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

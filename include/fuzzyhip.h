@@ -110,6 +110,18 @@ void fz_corpus_destroy(fz_corpus *c);
 
 int fz_corpus_info(const fz_corpus *c, fz_info *out);
 
+/*
+ * fz_corpus_save / fz_corpus_load -- a packed corpus file holding the built device layout (symbols,
+ * token ids, tiles, permutations, vocabulary), so that a process start is read + upload instead of
+ * tokenise + sort + transpose.  The reference re-fetches its lists from the database on every start
+ * (src/synapse_connection.py:103-121, called from src/synapse_agent.py:68-69) and has no such file;
+ * this is the natural unit to shard a 10^8-candidate corpus by.  `base_index` = ~0 keeps the base
+ * index the file was saved with.  Every offset, symbol and token end of the file is range-checked
+ * on load before it reaches the device.
+ */
+int fz_corpus_save(fz_corpus *c, const char *path);
+int fz_corpus_load(const char *path, int device, uint64_t base_index, fz_corpus **out);
+
 /* run later kernels on the caller's hipStream_t (NULL = the corpus' own stream) */
 int fz_set_stream(fz_corpus *c, void *hip_stream);
 

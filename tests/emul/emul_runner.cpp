@@ -4,11 +4,13 @@
 //              u32 cps[ncps], u64 offs[n+1], u32 qcps[nqcps], u64 qoffs[nq+1]
 //   op 0 fz_score_all -> u8[nq*n];  op 1 fz_distance_all -> u16[nq*n];
 //   op 2 fz_query_topk -> u64 idx[nq*k], i32 score[nq*k], u32 cnt[nq]
+//   op 4 fz_corpus_save + fz_corpus_load, then fz_score_all on the loaded corpus -> u8[nq*n]
 //   op 3 fz_query_topk_pair (scorer a | scorer b << 8; second corpus, queries and rank table appended) -> as op 2
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string>
 #include <vector>
 
 #include "fuzzyhip.h"
@@ -52,6 +54,24 @@ int main(int argc, char **argv)
         std::vector<uint16_t> out(nq * n ? nq * n : 1);
         rc = fz_distance_all(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, out.data());
         if (rc == FZ_OK) fwrite(out.data(), 2, nq * n, o);
+    } else if (op == 4) {     // save -> destroy -> load -> fz_score_all on the loaded corpus
+        std::string path = std::string(argv[2]) + ".corpus";
+        std::vector<uint8_t> out(nq * n ? nq * n : 1), warm(nq * n ? nq * n : 1);
+        if (sk != 0) rc = fz_score_all(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, warm.data());   // builds that view too
+        if (rc == FZ_OK) rc = fz_corpus_save(c, path.c_str());
+        fz_corpus_destroy(c);
+        c = nullptr;
+        if (rc == FZ_OK) rc = fz_corpus_load(path.c_str(), 0, ~0ull, &c);
+        if (rc == FZ_OK) rc = fz_score_all(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, out.data());
+        if (rc == FZ_OK) fwrite(out.data(), 1, nq * n, o);
+        if (rc == FZ_OK && h[3] == 1) {   // truncated copy must be refused, not crash
+            FILE *src = fopen(path.c_str(), "rb"); std::string tp = path + ".trunc"; FILE *dst = fopen(tp.c_str(), "wb");
+            fseek(src, 0, SEEK_END); long sz = ftell(src); fseek(src, 0, SEEK_SET);
+            std::vector<char> buf(sz * 2 / 3); if (fread(buf.data(), 1, buf.size(), src) != buf.size()) return 2;
+            fwrite(buf.data(), 1, buf.size(), dst); fclose(src); fclose(dst);
+            fz_corpus *bad = nullptr;
+            if (fz_corpus_load(tp.c_str(), 0, ~0ull, &bad) == FZ_OK) { fprintf(stderr, "truncated file was accepted\n"); return 4; }
+        }
     } else if (op == 3) {
         fz_corpus *cb = nullptr;
         rc = fz_corpus_create(cps_b.data(), offs_b.data(), n, 0, 0, &cb);
@@ -71,7 +91,7 @@ int main(int argc, char **argv)
         if (rc == FZ_OK) { fwrite(idx.data(), 8, nq * k, o); fwrite(sc.data(), 4, nq * k, o); fwrite(cnt.data(), 4, nq, o); }
     }
     fclose(o);
-    if (rc != FZ_OK) { fprintf(stderr, "scoring call: %d %s\n", rc, fz_last_error()); fz_corpus_destroy(c); return 3; }
+    if (rc != FZ_OK) { fprintf(stderr, "scoring call: %d %s\n", rc, fz_last_error()); if (c) fz_corpus_destroy(c); return 3; }
     fz_corpus_destroy(c);
     return 0;
 }

@@ -47,7 +47,7 @@ def _run(runner, tmp_path, op, sk, cand, queries, min_score=0, k=0, env=None):
     assert r.returncode == 0, r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
     raw = np.fromfile(out, dtype=np.uint8)
-    if op == 0:
+    if op in (0, 4):
         return raw.reshape(nq, n)
     if op == 1:
         return raw.view(np.uint16).reshape(nq, n)
@@ -240,3 +240,16 @@ def test_weighted_pair_many_ties(oracle, runner, tmp_path):
         exp.sort(key=lambda x: x[1], reverse=True)
         got = [(int(idx[qi, j]), vals[int(rank[qi, j]) - 1]) for j in range(int(cnt[qi]))]
         assert got == exp[:12], (q, got, exp[:12])
+
+
+def test_save_load_roundtrip(oracle, runner, tmp_path):
+    """packed corpus file: scores of the loaded corpus == oracle; a truncated file is refused"""
+    cps, offs = synth.make_corpus(300, max_chars=64, seed=51, vocab_size=40)
+    cand = synth.to_strings(cps, offs) + ["", "x" * 90, "a b c"]
+    queries = synth.make_queries(cps, offs, 4, seed=52) + ["", cand[1]]
+    for sk, orc in ((0, oracle.TOKEN_SET), (2, oracle.TOKEN_SORT), (3, oracle.PARTIAL)):
+        got = _run(runner, tmp_path, 4, sk, cand, queries, min_score=1 if sk == 0 else 0)
+        assert (got == _oracle_scores(oracle, orc, queries, cand)).all(), sk
+    wide, vocab = _wide_corpus(120, 53)
+    got = _run(runner, tmp_path, 4, 0, wide, [wide[3], vocab[2]])
+    assert (got == _oracle_scores(oracle, oracle.TOKEN_SET, [wide[3], vocab[2]], wide)).all()

@@ -171,3 +171,33 @@ def test_sharded_two_ranks_one_gpu():
     ret = mp.Manager().dict()
     mp.spawn(_sharded_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_packed_corpus_file_roundtrip(oracle, tmp_path):
+    """Corpus.save / Corpus.load (fz_corpus_save / fz_corpus_load): identical top-k, base index kept or rebased."""
+    import time
+    cps, offs = synth.make_corpus(200_000, max_chars=64, seed=91)
+    queries = synth.make_queries(cps, offs, 16, seed=92)
+    path = str(tmp_path / "shard0.fzc")
+    t0 = time.perf_counter()
+    with Corpus(cps, offs, base_index=1000) as c:
+        t_ingest = time.perf_counter() - t0
+        exp = c.topk(queries, 35, 10)
+        exp_ratio = c.score_all(queries[:2], _lib.RATIO)      # builds the raw view, which is then saved too
+        c.save(path)
+    t0 = time.perf_counter()
+    with Corpus.load(path) as c:
+        t_load = time.perf_counter() - t0
+        assert c.n == 200_000 and c.base_index == 1000
+        got = c.topk(queries, 35, 10)
+        for a, b in zip(got, exp):
+            assert (a == b).all()
+        assert (c.score_all(queries[:2], _lib.RATIO) == exp_ratio).all()
+    with Corpus.load(path, base_index=0) as c:
+        idx, score, cnt = c.topk(queries, 35, 10)
+        assert (idx + np.uint64(1000) == exp[0])[exp[1] > 0].all() and (score == exp[1]).all()
+    print(f"ingest {t_ingest:.3f} s, load {t_load:.3f} s for 200k candidates")
+    with open(path, "r+b") as f:
+        f.truncate(100_000)
+    with pytest.raises(_lib.FuzzyHipError):
+        Corpus.load(path)

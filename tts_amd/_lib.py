@@ -45,6 +45,8 @@ _SIGNATURES = {
     "fz_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "fz_corpus_create": (ctypes.c_int, [c_u32p, c_u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64,
                                         ctypes.POINTER(ctypes.c_void_p)]),
+    "fz_corpus_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "fz_corpus_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
     "fz_corpus_destroy": (None, [ctypes.c_void_p]),
     "fz_corpus_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(FzInfo)]),
     "fz_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

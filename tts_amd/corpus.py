@@ -52,6 +52,26 @@ class Corpus:
         cps, offs = pack_prepared(items)
         return cls(cps, offs, device=device, base_index=base_index)
 
+    # -- packed corpus file ----------------------------------------------------
+    def save(self, path: str) -> None:
+        """Write the built device layout to `path` (``fz_corpus_save``)."""
+        _lib.check(self._lib.fz_corpus_save(self._handle(), str(path).encode()))
+
+    @classmethod
+    def load(cls, path: str, device: int = 0, base_index: Optional[int] = None) -> "Corpus":
+        """Read + upload a file written by ``save``; ``base_index=None`` keeps the saved one."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        self.device = int(device)
+        _lib.check(self._lib.fz_corpus_load(str(path).encode(), self.device,
+                                            (1 << 64) - 1 if base_index is None else int(base_index),
+                                            ctypes.byref(self._h)))
+        inf = self.info()
+        self.n = int(inf["n"])
+        self.base_index = int(inf["base_index"])
+        return self
+
     # -- lifetime ------------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -113,6 +113,7 @@ struct View {
     bool wide = false;                                    // > 254 distinct code points: 16-bit symbols
     uint32_t npad = 0, ntiles = 0, max_ndw = 0, max_len = 0, max_tok = 0, alphabet = 2;
     uint64_t total_symbols = 0, total_tokens = 0, device_bytes = 0;
+    uint64_t n_sym_words = 0, n_tok_slots = 0;            // lengths of d_sym and d_tokid / d_tokend
     std::vector<uint16_t> sym_of_cp;                      // code point -> symbol (0 = not in corpus)
     uint32_t *d_sym = nullptr, *d_tokid = nullptr, *d_orig_of_phys = nullptr, *d_phys_of_orig = nullptr;
     uint16_t *d_tokend = nullptr;
@@ -246,6 +247,23 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
     delete c;
 }
 
+// tile indices by kernel: stream kernel with one / two pattern words, general kernel for the rest
+static int upload_tile_lists(View &v, const std::vector<FzTile> &tiles)
+{
+    std::vector<uint32_t> ts1, ts2, tslow;
+    for (uint32_t t = 0; t < v.ntiles; ++t) {
+        // the stream kernel keeps one Peq row per symbol byte: 8-bit symbols only
+        if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
+        else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
+        else tslow.push_back(t);
+    }
+    v.n_s1 = (uint32_t)ts1.size(); v.n_s2 = (uint32_t)ts2.size(); v.n_slow = (uint32_t)tslow.size();
+    int rc;
+    if ((rc = upload(&v.d_tiles_s1, ts1, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload(&v.d_tiles_s2, ts2, &v.device_bytes)) != FZ_OK) return rc;
+    return upload(&v.d_tiles_slow, tslow, &v.device_bytes);
+}
+
 // Builds one device view: reduce every candidate to the text its scorer compares, map code points
 // to 8-bit symbols, sort by (symbol dwords, tokens, original index), cut into 64-candidate tiles,
 // transpose to symbol-major order and upload.
@@ -363,6 +381,7 @@ static int build_view(fz_corpus *c, int kind)
         sym_words += (uint64_t)ndw * 64; tok_slots += (uint64_t)ntok * 64;
         v.max_ndw = std::max(v.max_ndw, ndw);
     }
+    v.n_sym_words = sym_words; v.n_tok_slots = tok_slots;
     std::vector<uint32_t> h_sym(sym_words, 0u);
     std::vector<uint32_t> h_tokid(tok_slots, FZ_TOK_NONE);
     std::vector<uint16_t> h_tokend(tok_slots, 0);
@@ -394,20 +413,12 @@ static int build_view(fz_corpus *c, int kind)
     if ((rc = upload(&v.d_tiles, tiles, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_orig_of_phys, v.h_orig_of_phys, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_phys_of_orig, phys_of_orig, &v.device_bytes)) != FZ_OK) return rc;
-    std::vector<uint32_t> ts1, ts2, tslow;
-    for (uint32_t t = 0; t < v.ntiles; ++t) {
-        // the stream kernel keeps one Peq row per symbol byte: 8-bit symbols only
-        if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
-        else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
-        else tslow.push_back(t);
-    }
-    v.n_s1 = (uint32_t)ts1.size(); v.n_s2 = (uint32_t)ts2.size(); v.n_slow = (uint32_t)tslow.size();
-    if ((rc = upload(&v.d_tiles_s1, ts1, &v.device_bytes)) != FZ_OK) return rc;
-    if ((rc = upload(&v.d_tiles_s2, ts2, &v.device_bytes)) != FZ_OK) return rc;
-    if ((rc = upload(&v.d_tiles_slow, tslow, &v.device_bytes)) != FZ_OK) return rc;
+    if ((rc = upload_tile_lists(v, tiles)) != FZ_OK) return rc;
     v.built = true;
     return FZ_OK;
 }
+
+static int finish_create(fz_corpus *c);
 
 static int corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
                          uint64_t base_index, int eager_view, fz_corpus **out)
@@ -435,19 +446,27 @@ static int corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, 
     c->h_offs.resize(n + 1);
     for (uint64_t i = 0; i <= n; ++i) c->h_offs[i] = n ? offs[i] - lo : 0;
     int rc = build_view(c, eager_view);
+    if (rc == FZ_OK) rc = finish_create(c);
     if (rc != FZ_OK) { fz_corpus_destroy(c); return rc; }
+    *out = c;
+    return FZ_OK;
+}
+
+// score tables, tuning knobs, the corpus' own stream: common tail of create and load
+static int finish_create(fz_corpus *c)
+{
+    int rc = FZ_OK;
     for (int form = 0; form < 2 && rc == FZ_OK; ++form) {
         uint64_t unused = 0;
         rc = upload(&c->d_score_tab[form], make_score_table(form == 0 ? g_ties_norm_distance : g_ties_norm_sim), &unused);
     }
-    if (rc != FZ_OK) { fz_corpus_destroy(c); return rc; }
+    if (rc != FZ_OK) return rc;
     if (const char *e = getenv("FUZZYHIP_NO_STREAM")) c->use_stream = !(e[0] == '1');
     if (const char *e = getenv("FUZZYHIP_STREAM_WAVES")) c->stream_waves = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("FUZZYHIP_STREAM_BLOCKS")) c->stream_blocks = (uint32_t)std::max(1, atoi(e));
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { fz_corpus_destroy(c); return fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     c->stream = c->own_stream;
-    *out = c;
     return FZ_OK;
 }
 
@@ -455,6 +474,195 @@ extern "C" int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint6
                                 uint64_t base_index, fz_corpus **out)
 {
     return corpus_create(cps, offs, n, device, base_index, VIEW_SET, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// packed corpus file: the built device views, so that a process start is read + upload instead of
+// tokenise + sort + transpose (candidate provenance: src/synapse_connection.py:103-121)
+// ---------------------------------------------------------------------------------------------
+// layout: "FZCORP01" | u64 n | u64 base | u64 vocab count | vocab tokens {u32 len, u32 cps[len]} in id
+// order | input {u64 ncps, u32 cps[], u64 offs[n+1]} | per view {u32 built; if built: header of u64s,
+// sparse alphabet {u32 cp, u32 sym}, then the arrays exactly as they sit in HBM}.
+static const char kFileMagic[8] = {'F', 'Z', 'C', 'O', 'R', 'P', '0', '1'};
+
+template <typename T>
+static bool put(FILE *f, const T *p, size_t n) { return n == 0 || fwrite(p, sizeof(T), n, f) == n; }
+template <typename T>
+static bool get(FILE *f, T *p, size_t n) { return n == 0 || fread(p, sizeof(T), n, f) == n; }
+
+template <typename T>
+static int dump_device(FILE *f, const T *d, size_t n)
+{
+    std::vector<T> h(n);
+    if (n) HIP_TRY(hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
+    if (!put(f, h.data(), n)) return fail(FZ_ERR_INVALID, "write failed");
+    return FZ_OK;
+}
+
+template <typename T>
+static int load_device(FILE *f, T **d, size_t n, uint64_t *bytes)
+{
+    std::vector<T> h(n);
+    if (!get(f, h.data(), n)) return fail(FZ_ERR_INVALID, "corpus file is truncated");
+    return upload(d, h, bytes);
+}
+
+extern "C" int fz_corpus_save(fz_corpus *c, const char *path)
+{
+    if (!c || !path) return fail(FZ_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(FZ_ERR_INVALID, "cannot open %s for writing", path);
+    int rc = FZ_OK;
+    bool ok = put(f, kFileMagic, 8);
+    const uint64_t hdr[3] = {c->n, c->base, (uint64_t)c->vocab_store.size()};
+    ok = ok && put(f, hdr, 3);
+    for (const std::u32string &t : c->vocab_store) {         // id order: ids are handed out in push order
+        const uint32_t len = (uint32_t)t.size();
+        ok = ok && put(f, &len, 1) && put(f, reinterpret_cast<const uint32_t *>(t.data()), len);
+    }
+    const uint64_t ncps = c->h_cps.size();
+    ok = ok && put(f, &ncps, 1) && put(f, c->h_cps.data(), ncps) && put(f, c->h_offs.data(), c->h_offs.size());
+    for (int k = 0; k < N_VIEWS && ok && rc == FZ_OK; ++k) {
+        const View &v = c->views[k];
+        const uint32_t built = v.built ? 1u : 0u;
+        ok = ok && put(f, &built, 1);
+        if (!built) continue;
+        std::vector<uint32_t> alpha;
+        for (uint32_t cp = 0; cp < 0x110000u; ++cp)
+            if (v.sym_of_cp[cp]) { alpha.push_back(cp); alpha.push_back(v.sym_of_cp[cp]); }
+        const uint64_t vh[16] = {v.wide, v.npad, v.ntiles, v.max_ndw, v.max_len, v.max_tok, v.alphabet,
+                                 v.total_symbols, v.total_tokens, v.n_sym_words, v.n_tok_slots,
+                                 v.n_s1, v.n_s2, v.n_slow, (uint64_t)alpha.size(), 0};
+        ok = ok && put(f, vh, 16) && put(f, alpha.data(), alpha.size());
+        if (!ok) break;
+        if ((rc = dump_device(f, v.d_sym, v.n_sym_words)) != FZ_OK) break;
+        if ((rc = dump_device(f, v.d_tokid, v.n_tok_slots)) != FZ_OK) break;
+        if ((rc = dump_device(f, v.d_tokend, v.n_tok_slots)) != FZ_OK) break;
+        if ((rc = dump_device(f, v.d_tiles, v.ntiles)) != FZ_OK) break;
+        if ((rc = dump_device(f, v.d_orig_of_phys, v.npad)) != FZ_OK) break;
+        if ((rc = dump_device(f, v.d_phys_of_orig, (size_t)c->n)) != FZ_OK) break;
+    }
+    if (fclose(f) != 0) ok = false;
+    if (rc != FZ_OK) return rc;
+    if (!ok) return fail(FZ_ERR_INVALID, "write to %s failed", path);
+    return FZ_OK;
+}
+
+static int finish_create(fz_corpus *c);
+
+extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index, fz_corpus **out)
+{
+    if (!out || !path) return fail(FZ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FZ_ERR_NO_DEVICE, "no HIP device visible: libfuzzyhip has no CPU path");
+    if (device < 0 || device >= ndev) return fail(FZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+    std::call_once(g_ties_once, make_tie_tables);
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(FZ_ERR_INVALID, "cannot open %s", path);
+    fz_corpus *c = new fz_corpus();
+    auto bad = [&](const char *why) { fclose(f); fz_corpus_destroy(c); return fail(FZ_ERR_INVALID, "%s: %s", path, why); };
+    char magic[8]; uint64_t hdr[3];
+    if (!get(f, magic, 8) || memcmp(magic, kFileMagic, 8) != 0) return bad("not a packed corpus file (magic FZCORP01)");
+    if (!get(f, hdr, 3)) return bad("truncated header");
+    c->device = device; c->n = hdr[0];
+    c->base = base_index == ~0ull ? hdr[1] : base_index;      // ~0: keep the base index the file was saved with
+    if (c->n >= 0xFFFFFFFFull - 64 || c->base + c->n > FZ_IDX_MASK) return bad("candidate count or base index out of range");
+    for (uint64_t i = 0; i < hdr[2]; ++i) {
+        uint32_t len;
+        if (!get(f, &len, 1) || len > FZ_MAX_CAND_LEN) return bad("bad vocabulary entry");
+        std::u32string t(len, U'\0');
+        if (!get(f, reinterpret_cast<uint32_t *>(t.data()), len)) return bad("truncated vocabulary");
+        c->vocab_store.push_back(std::move(t));
+        c->vocab.emplace(Tok(c->vocab_store.back()), (uint32_t)i);
+    }
+    uint64_t ncps;
+    if (!get(f, &ncps, 1) || ncps > (1ull << 40)) return bad("bad input section");
+    c->h_cps.resize(ncps); c->h_offs.resize(c->n + 1);
+    if (!get(f, c->h_cps.data(), ncps) || !get(f, c->h_offs.data(), c->n + 1)) return bad("truncated input section");
+    for (uint64_t i = 0; i < c->n; ++i)
+        if (c->h_offs[i + 1] < c->h_offs[i] || c->h_offs[i + 1] > ncps) return bad("offsets out of range");
+    int rc = FZ_OK;
+    for (int k = 0; k < N_VIEWS; ++k) {
+        View &v = c->views[k];
+        uint32_t built;
+        if (!get(f, &built, 1)) return bad("truncated view table");
+        if (!built) continue;
+        uint64_t vh[16];
+        if (!get(f, vh, 16)) return bad("truncated view header");
+        v.wide = vh[0] != 0; v.npad = (uint32_t)vh[1]; v.ntiles = (uint32_t)vh[2]; v.max_ndw = (uint32_t)vh[3];
+        v.max_len = (uint32_t)vh[4]; v.max_tok = (uint32_t)vh[5]; v.alphabet = (uint32_t)vh[6];
+        v.total_symbols = vh[7]; v.total_tokens = vh[8]; v.n_sym_words = vh[9]; v.n_tok_slots = vh[10];
+        v.n_s1 = (uint32_t)vh[11]; v.n_s2 = (uint32_t)vh[12]; v.n_slow = (uint32_t)vh[13];
+        if (v.npad != (uint32_t)((c->n + FZ_TILE - 1) / FZ_TILE) * FZ_TILE || v.ntiles != v.npad / FZ_TILE ||
+            v.alphabet > 0x10000u || v.n_sym_words > 0xFFFFFFFFull || v.n_tok_slots > 0xFFFFFFFFull ||
+            vh[14] > 2ull * 0x110000ull || (vh[14] & 1ull))
+            return bad("inconsistent view header");
+        std::vector<uint32_t> alpha(vh[14]);
+        if (!get(f, alpha.data(), alpha.size())) return bad("truncated alphabet");
+        v.sym_of_cp.assign(0x110000, 0);
+        for (size_t i = 0; i < alpha.size(); i += 2) {
+            if (alpha[i] >= 0x110000u || alpha[i + 1] >= v.alphabet) return bad("bad alphabet entry");
+            v.sym_of_cp[alpha[i]] = (uint16_t)alpha[i + 1];
+        }
+        std::vector<FzTile> tiles(v.ntiles);
+        {
+            std::vector<uint32_t> h_sym(v.n_sym_words), h_tokid(v.n_tok_slots);
+            std::vector<uint16_t> h_tokend(v.n_tok_slots);
+            if (!get(f, h_sym.data(), h_sym.size()) || !get(f, h_tokid.data(), h_tokid.size()) ||
+                !get(f, h_tokend.data(), h_tokend.size()) || !get(f, tiles.data(), tiles.size()))
+                return bad("truncated view arrays");
+            // the kernels trust these values (LDS rows are indexed by symbol, keep-masks by token end):
+            // check every one of them before anything reaches the device
+            const uint32_t spd = v.wide ? 2u : 4u, sbits = 32u / spd, smask = v.wide ? 0xFFFFu : 0xFFu;
+            for (const FzTile &t : tiles) {
+                if ((uint64_t)t.coff + (uint64_t)t.ndw * 64 > v.n_sym_words || (uint64_t)t.toff + (uint64_t)t.ntok * 64 > v.n_tok_slots ||
+                    t.ndw > v.max_ndw)
+                    return bad("tile table points outside the symbol or token arrays");
+                for (uint64_t i = t.coff; i < (uint64_t)t.coff + (uint64_t)t.ndw * 64; ++i)
+                    for (uint32_t k = 0; k < spd; ++k)
+                        if (((h_sym[i] >> (sbits * k)) & smask) >= v.alphabet) return bad("symbol outside the alphabet");
+                for (uint32_t l = 0; l < FZ_TILE; ++l) {
+                    uint32_t prev = 0;
+                    for (uint32_t i = 0; i < t.ntok; ++i) {
+                        const uint32_t e = h_tokend[t.toff + (uint64_t)i * 64 + l];
+                        if (e < prev || e > (uint32_t)t.ndw * spd) return bad("token end outside its candidate");
+                        prev = e;
+                    }
+                }
+            }
+            if ((rc = upload(&v.d_sym, h_sym, &v.device_bytes)) != FZ_OK) break;
+            if ((rc = upload(&v.d_tokid, h_tokid, &v.device_bytes)) != FZ_OK) break;
+            if ((rc = upload(&v.d_tokend, h_tokend, &v.device_bytes)) != FZ_OK) break;
+            if ((rc = upload(&v.d_tiles, tiles, &v.device_bytes)) != FZ_OK) break;
+        }
+        v.h_orig_of_phys.resize(v.npad);
+        if (!get(f, v.h_orig_of_phys.data(), v.npad)) return bad("truncated permutation");
+        for (uint32_t ph = 0; ph < v.npad; ++ph)
+            if (ph < c->n ? v.h_orig_of_phys[ph] >= c->n : v.h_orig_of_phys[ph] != 0xFFFFFFFFu) return bad("bad permutation");
+        if ((rc = upload(&v.d_orig_of_phys, v.h_orig_of_phys, &v.device_bytes)) != FZ_OK) break;
+        {
+            std::vector<uint32_t> pofo(c->n);
+            if (!get(f, pofo.data(), pofo.size())) return bad("truncated permutation");
+            for (uint64_t o = 0; o < c->n; ++o)
+                if (pofo[o] >= c->n || v.h_orig_of_phys[pofo[o]] != o) return bad("permutations do not invert each other");
+            if ((rc = upload(&v.d_phys_of_orig, pofo, &v.device_bytes)) != FZ_OK) break;
+        }
+        rc = upload_tile_lists(v, tiles);
+        if (rc != FZ_OK) break;
+        v.built = true;
+    }
+    fclose(f);
+    if (rc == FZ_OK && !c->views[VIEW_SET].built) rc = build_view(c, VIEW_SET);
+    if (rc == FZ_OK) rc = finish_create(c);
+    if (rc != FZ_OK) { fz_corpus_destroy(c); return rc; }
+    *out = c;
+    return FZ_OK;
 }
 
 extern "C" int fz_corpus_info(const fz_corpus *c, fz_info *o)
