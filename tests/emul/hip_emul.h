@@ -143,6 +143,11 @@ static inline T __shfl_down(T v, unsigned off, int = 64)
     uint64_t r = emul::wave_exchange((uint64_t)v, lane + off < emul::WAVE ? lane + off : lane, &ok);
     return (T)r;
 }
+template <typename T>
+static inline T __shfl(T v, int src_lane, int = 64)
+{
+    return (T)emul::wave_exchange((uint64_t)v, (uint32_t)src_lane & 63u);
+}
 static inline uint64_t __ballot(bool pred)
 {
     emul::WaveState &w = emul::my_wave();
@@ -155,6 +160,7 @@ static inline uint64_t __ballot(bool pred)
     w.bar.wait();
     return m;
 }
+static inline uint64_t wall_clock64() { return 0; }
 static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)

@@ -117,6 +117,7 @@ struct FzSelectParams {
     uint64_t *out_keys;       // [rows][k]
     uint32_t *out_cnt;        // [rows] or null
     uint32_t flat;            // 1: every passing score counts as min_score, so the order is by index only
+    uint64_t *dbg;            // diagnostics (FUZZYHIP_SELECT_DEBUG=1): [rows][8] phase timestamps, or null
 };
 
 // ---- two scorers combined through a rank table (fz_query_topk_pair) ------------------------------

@@ -1138,7 +1138,25 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             sp.min_score = min_score; sp.k = k; sp.base_index = c->base;
             sp.out_keys = d_keys + q0 * k; sp.out_cnt = d_cnt ? d_cnt + q0 : nullptr;
             sp.flat = o.flat;
+            uint64_t *d_dbg = nullptr;
+            if (getenv("FUZZYHIP_SELECT_DEBUG")) {
+                HIP_TRY(hipMalloc((void **)&d_dbg, (size_t)rows * 64));
+                HIP_TRY(hipMemsetAsync(d_dbg, 0, (size_t)rows * 64, st));
+                sp.dbg = d_dbg;
+            }
             HIP_TRY(fz_launch_select(sp, rows, st));
+            if (d_dbg) {      // diagnostics only: phase times of the slowest rows (100 MHz wall clock)
+                std::vector<uint64_t> h((size_t)rows * 8);
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+                (void)hipFree(d_dbg);
+                uint32_t worst = 0;
+                for (uint32_t r = 0; r < rows; ++r) if (h[r * 8 + 4] - h[r * 8] > h[worst * 8 + 4] - h[worst * 8]) worst = r;
+                const uint64_t *w = &h[(size_t)worst * 8];
+                fprintf(stderr, "[select dbg] slowest row %u: passA %.1f us, passB %.1f us, ties %.1f us, sort %.1f us; c_eq %llu need %llu sstar %llu\n",
+                        worst, (w[1] - w[0]) / 100.0, (w[2] - w[1]) / 100.0, (w[3] - w[2]) / 100.0, (w[4] - w[3]) / 100.0,
+                        (unsigned long long)w[5], (unsigned long long)w[6], (unsigned long long)w[7]);
+            }
             c->timing.select_launches++;
             hipEvent_t e2 = get_event(c, ev++);
             if (!e2) return fail(FZ_ERR_HIP, "hipEventCreate failed");

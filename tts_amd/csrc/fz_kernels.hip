@@ -676,8 +676,11 @@ hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_
 // ---------------------------------------------------------------------------------------------
 // top-k selection
 // ---------------------------------------------------------------------------------------------
-#define SEL_THREADS 256u
+#define SEL_THREADS 512u       // fz_select_topk: 8 waves per row (4 rows per CU resident: 1000 rows in one round)
+#define SEL_WAVES (SEL_THREADS / 64u)
+#define SEL16_THREADS 256u     // fz_select16_topk: one thread per histogram bin
 #define SEL_TIECAP 2048u
+#define SEL_VEC 4u            // 16-byte vectors per thread per iteration of the row passes
 
 __device__ __forceinline__ uint64_t fz_local_key(uint32_t score, uint32_t orig)
 {
@@ -711,6 +714,28 @@ __device__ __forceinline__ void fz_sel_update(uint32_t *s_hist, uint32_t *s_cum,
         if (s_cum[tid] >= k && s_cum[tid + 1u] < k && tid > s_misc[0]) s_misc[0] = tid;
     }
     __syncthreads();
+    // Once the cut value itself holds more than SEL_TIECAP + k candidates, further ones with that value
+    // change nothing (enough ties for any `need`, and too many to sort): count only better scores from
+    // here on.  Without this a row with 10^5 ties at the cut spends its whole pass in the histogram.
+    if (tid == 0u) s_misc[8] = s_misc[0] + (s_hist[s_misc[0]] > SEL_TIECAP + k ? 1u : 0u);
+    __syncthreads();
+}
+
+// Wave-aggregated histogram add: the lanes of a wave that hold the same bin share ONE LDS atomic.
+// A row where tens of thousands of candidates tie on one score (a one-token query that is a subset
+// of 10 % of the corpus) otherwise serialises on a single LDS address.  Every lane of the wave must
+// call this (convergent); `valid` says whether the lane has something to add.
+__device__ __forceinline__ void fz_hist_add(uint32_t *hist, uint32_t bin, bool valid)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t todo = __ballot(valid);
+    while (todo != 0ull) {
+        const uint32_t first = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t b0 = (uint32_t)__shfl((int)bin, (int)first, 64);
+        const uint64_t same = __ballot(valid && bin == b0);
+        if (lane == first) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
 }
 
 template <typename T, bool DESC>
@@ -732,11 +757,11 @@ __device__ __forceinline__ void fz_bitonic(T *a, uint32_t P)
     }
 }
 
-__global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
+__global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
 {
     __shared__ uint32_t s_hist[128];
     __shared__ uint32_t s_cum[129];
-    __shared__ uint32_t s_misc[8];          // 0: tlow  1: scratch  2: n_gt  3: n_tie  4..7: wave counts
+    __shared__ uint32_t s_misc[16 + SEL_WAVES];   // 0: tlow  1: scratch  2: n_gt  3: n_tie  8: count filter  16..: wave counts
     __shared__ uint64_t s_keys[FZ_MAX_K];
     __shared__ uint32_t s_ties[SEL_TIECAP];
 
@@ -746,32 +771,50 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
     const uint32_t min_score = p.min_score < 0 ? 0u : (uint32_t)p.min_score;
 
     if (tid < 128u) s_hist[tid] = 0u;
-    if (tid == 0u) { s_misc[0] = min_score; s_misc[2] = 0u; s_misc[3] = 0u; }
+    if (tid == 0u) { s_misc[0] = min_score; s_misc[2] = 0u; s_misc[3] = 0u; s_misc[8] = min_score; }
     __syncthreads();
+#define FZ_DBG(i) do { if (p.dbg && tid == 0u) p.dbg[(uint64_t)row * 8u + (i)] = (uint64_t)wall_clock64(); } while (0)
+    FZ_DBG(0);
 
     // ---- pass A: histogram of the scores that can still matter ------------------------------
-    const uint32_t per_iter = SEL_THREADS * 16u;
+    // Each thread takes SEL_VEC 16-byte vectors per iteration (all loads issued before the first use)
+    // and tests a dword with one SWAR expression before it looks at its bytes: with t in 1..128,
+    // ((x + 0x01010101 * (128 - t)) | x) & 0x80808080 is non-zero iff some byte of x is >= t (a carry
+    // out of a byte >= 128 can only add false positives; the byte loop below is exact).
+    const uint32_t per_iter = SEL_THREADS * 16u * SEL_VEC;
     const uint32_t niter = (n + per_iter - 1u) / per_iter;
     for (uint32_t it = 0; it < niter; ++it) {
-        const uint32_t base = (it * SEL_THREADS + tid) * 16u;
-        if (base < n) {
-            const uint32_t tlow = s_misc[0];
-            const uint4 v = *reinterpret_cast<const uint4 *>(sc + base);
-            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t tlow = s_misc[8];                     // count scores >= this (<= 101)
+        const uint32_t add = 0x01010101u * (128u - (tlow ? tlow : 1u));
+        uint4 v[SEL_VEC];
+#pragma unroll
+        for (uint32_t j = 0; j < SEL_VEC; ++j) {
+            const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
+            v[j] = base < n ? *reinterpret_cast<const uint4 *>(sc + base) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < SEL_VEC; ++j) {
+            const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
+            const uint32_t wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;             // a byte > 100 is not a score: skipped
+                // one flag bit (7, 15, 23, 31) per candidate byte; the lane then visits only those bytes
+                uint32_t m = tlow != 0u ? (((wv[a] + add) | wv[a]) & 0x80808080u) : 0x80808080u;
+                while (__ballot(m != 0u) != 0ull) {                      // wave-uniform trip count
+                    const bool on = m != 0u;
+                    const uint32_t sh = on ? (uint32_t)__builtin_ctz(m) - 7u : 0u;
+                    m &= m - 1u;
+                    uint32_t s = (wv[a] >> sh) & 0xFFu;                  // a byte > 100 is not a score: skipped
                     if (p.flat && s >= min_score) s = s <= 100u ? min_score : s;   // index order only
-                    if (s >= tlow && s <= 100u && base + (uint32_t)(4 * a + b) < n) atomicAdd(&s_hist[s], 1u);
+                    fz_hist_add(s_hist, s, on && s >= tlow && s <= 100u && base + (uint32_t)(4 * a) + (sh >> 3) < n);
                 }
             }
         }
-        if ((it & 7u) == 7u) fz_sel_update(s_hist, s_cum, s_misc, k);
+        if ((it & 1u) == 1u) fz_sel_update(s_hist, s_cum, s_misc, k);
     }
     fz_sel_update(s_hist, s_cum, s_misc, k);
 
+    FZ_DBG(1);
     const uint32_t sstar = s_misc[0];                    // k-th best score (or min_score)
     const uint32_t n_gt = s_cum[sstar + 1u];             // strictly better: all of them are results
     const uint32_t c_eq = s_hist[sstar];                 // ties at the cut
@@ -780,25 +823,38 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
     const bool few_ties = c_eq <= SEL_TIECAP;
 
     // ---- pass B: collect ----------------------------------------------------------------------
-    for (uint32_t it = 0; it < niter; ++it) {
-        const uint32_t base = (it * SEL_THREADS + tid) * 16u;
-        if (base < n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(sc + base);
-            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+    {
+        // ties are collected here only when they are few enough to sort; otherwise look at better scores only
+        const uint32_t bfil = (few_ties && need > 0u) ? sstar : sstar + 1u;
+        const uint32_t add = 0x01010101u * (128u - (bfil ? bfil : 1u));
+        for (uint32_t it = 0; it < niter; ++it) {
+            uint4 v[SEL_VEC];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+            for (uint32_t j = 0; j < SEL_VEC; ++j) {
+                const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
+                v[j] = base < n ? *reinterpret_cast<const uint4 *>(sc + base) : uint4{0u, 0u, 0u, 0u};
+            }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    uint32_t s = (wv[a] >> (8 * b)) & 0xFFu;
-                    if (p.flat && s >= min_score) s = s <= 100u ? min_score : s;
-                    const uint32_t ph = base + (uint32_t)(4 * a + b);
-                    if (ph < n && s >= sstar && s <= 100u) {
-                        if (s > sstar) {
-                            uint32_t pos = atomicAdd(&s_misc[2], 1u);
-                            s_keys[pos] = fz_local_key(s, p.orig_of_phys[ph]);
-                        } else if (few_ties && need > 0u) {
-                            uint32_t pos = atomicAdd(&s_misc[3], 1u);
-                            s_ties[pos] = p.orig_of_phys[ph];
+            for (uint32_t j = 0; j < SEL_VEC; ++j) {
+                const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
+                const uint32_t wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    uint32_t m = bfil != 0u ? (((wv[a] + add) | wv[a]) & 0x80808080u) : 0x80808080u;
+                    while (m != 0u) {
+                        const uint32_t sh = (uint32_t)__builtin_ctz(m) - 7u;
+                        m &= m - 1u;
+                        uint32_t s = (wv[a] >> sh) & 0xFFu;
+                        if (p.flat && s >= min_score) s = s <= 100u ? min_score : s;
+                        const uint32_t ph = base + (uint32_t)(4 * a) + (sh >> 3);
+                        if (ph < n && s >= sstar && s <= 100u) {
+                            if (s > sstar) {
+                                uint32_t pos = atomicAdd(&s_misc[2], 1u);
+                                s_keys[pos] = fz_local_key(s, p.orig_of_phys[ph]);
+                            } else if (few_ties && need > 0u) {
+                                uint32_t pos = atomicAdd(&s_misc[3], 1u);
+                                s_ties[pos] = p.orig_of_phys[ph];
+                            }
                         }
                     }
                 }
@@ -807,6 +863,7 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
     }
     __syncthreads();
 
+    FZ_DBG(2);
     // ---- ties at the cut: the `need` smallest original indices ------------------------------
     if (need > 0u) {
         if (few_ties) {
@@ -828,18 +885,19 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
                     pred = p.flat ? (s >= sstar && s <= 100u) : (s == sstar);    // flat: sstar == min_score
                 }
                 const uint64_t bal = __ballot(pred);
-                if (lane == 0u) s_misc[4 + wave] = (uint32_t)__popcll(bal);
+                if (lane == 0u) s_misc[16 + wave] = (uint32_t)__popcll(bal);
                 __syncthreads();
                 uint32_t before = found;
-                for (uint32_t w = 0; w < wave; ++w) before += s_misc[4 + w];
+                for (uint32_t w = 0; w < wave; ++w) before += s_misc[16 + w];
                 const uint32_t mine = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                 if (pred && mine < need) s_ties[mine] = o;
-                found += s_misc[4] + s_misc[5] + s_misc[6] + s_misc[7];
+                for (uint32_t w = 0; w < SEL_WAVES; ++w) found += s_misc[16 + w];
                 __syncthreads();
             }
         }
         for (uint32_t i = tid; i < need; i += blockDim.x) s_keys[n_gt + i] = fz_local_key(sstar, s_ties[i]);
     }
+    FZ_DBG(3);
     const uint32_t total = n_gt + need;
     uint32_t P = 2u;
     while (P < total) P <<= 1;
@@ -847,6 +905,8 @@ __global__ __launch_bounds__(256) void fz_select_topk(FzSelectParams p)
     for (uint32_t i = total + tid; i < P; i += blockDim.x) s_keys[i] = 0ull;
     __syncthreads();
     fz_bitonic<uint64_t, true>(s_keys, P);
+    FZ_DBG(4);
+    if (p.dbg && tid == 0u) { p.dbg[(uint64_t)row * 8u + 5u] = c_eq; p.dbg[(uint64_t)row * 8u + 6u] = need; p.dbg[(uint64_t)row * 8u + 7u] = sstar; }
 
     for (uint32_t i = tid; i < k; i += blockDim.x) {
         uint64_t out = 0ull;
@@ -919,9 +979,10 @@ __global__ __launch_bounds__(256) void fz_select16_topk(FzSelect16Params p)
     s_hist[tid] = 0u;
     if (tid == 0u) { s_misc[0] = minr >> 8; s_misc[1] = minr; s_misc[2] = 0u; s_misc[3] = 0u; }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += blockDim.x) {
-        const uint32_t r = rk[i];
-        if (r >= minr) atomicAdd(&s_hist[r >> 8], 1u);
+    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {        // uniform trip count: fz_hist_add is convergent
+        const uint32_t i = i0 + tid;
+        const uint32_t r = i < n ? rk[i] : 0u;
+        fz_hist_add(s_hist, r >> 8, i < n && r >= minr);
     }
     fz_sel16_suffix(s_hist, s_cum, s_part);
     if (s_cum[tid] >= k && s_cum[tid + 1u] < k && tid > s_misc[0]) s_misc[0] = tid;   // at most one bin
@@ -933,9 +994,10 @@ __global__ __launch_bounds__(256) void fz_select16_topk(FzSelect16Params p)
     // ---- pass 2: low bytes inside bin B ------------------------------------------------------
     s_hist[tid] = 0u;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += blockDim.x) {
-        const uint32_t r = rk[i];
-        if (r >= minr && (r >> 8) == B) atomicAdd(&s_hist[r & 255u], 1u);
+    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+        const uint32_t i = i0 + tid;
+        const uint32_t r = i < n ? rk[i] : 0u;
+        fz_hist_add(s_hist, r & 255u, i < n && r >= minr && (r >> 8) == B);
     }
     fz_sel16_suffix(s_hist, s_cum, s_part);
     {
@@ -977,7 +1039,7 @@ __global__ __launch_bounds__(256) void fz_select16_topk(FzSelect16Params p)
         } else {
             // many ties: candidates are in ORIGINAL order here, so the first `need` tied ones win
             uint32_t found = 0u;
-            for (uint32_t o0 = 0u; o0 < n && found < need; o0 += SEL_THREADS) {
+            for (uint32_t o0 = 0u; o0 < n && found < need; o0 += SEL16_THREADS) {
                 const uint32_t o = o0 + tid;
                 const bool pred = o < n && rk[o] == (uint16_t)rstar;
                 const uint64_t bal = __ballot(pred);
@@ -1121,6 +1183,6 @@ hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_
 hipError_t fz_launch_select16(const FzSelect16Params &p, uint32_t rows, hipStream_t st)
 {
     if (rows == 0u || p.k == 0u) return hipSuccess;
-    hipLaunchKernelGGL(fz_select16_topk, dim3(rows), dim3(SEL_THREADS), 0, st, p);
+    hipLaunchKernelGGL(fz_select16_topk, dim3(rows), dim3(SEL16_THREADS), 0, st, p);
     return hipGetLastError();
 }
