@@ -48,6 +48,9 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
 }
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 2; return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 
 // ---- kernel language ----------------------------------------------------------------------------
@@ -163,11 +166,16 @@ static inline uint64_t __ballot(bool pred)
 static inline uint64_t wall_clock64() { return 0; }
 static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
 
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
-static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // callers pass wave-uniform values
+static inline int __builtin_amdgcn_readfirstlane(int x)    // every live lane of the wave calls it
+{
+    return (int)(uint32_t)emul::wave_exchange((uint64_t)(uint32_t)x, 0u);
+}
 static inline uint32_t __builtin_amdgcn_bitop3_b32(uint32_t a, uint32_t b, uint32_t c, uint32_t tt)
 {
     uint32_t r = 0;

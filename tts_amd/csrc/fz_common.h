@@ -79,6 +79,8 @@ struct FzScoreParams {
 //           dropped on the host: they cannot change the LCS state.
 #define FZ_STREAM_MAX_TOK 8u      // token slots of an eligible tile
 #define FZ_STREAM_MAX_ROWS 63u    // Peq rows (distinct text symbols of one launch), row byte = 4*row < 256
+#define FZ_STREAM_QUEUES 32u      // work queues of one launch (each a contiguous range of items)
+#define FZ_STREAM_QPAD 64u        // u32 words between two queue counters (256 B: one counter per cache line)
 #define FZ_STREAM_TAB 128u        // score table is [FZ_STREAM_TAB][FZ_STREAM_TAB]: T[L][d], L, d < 128
 #define FZ_QTOK_UNKNOWN 0xFFFFFFFEu   // token that is not in the corpus vocabulary
 #define FZ_QTOK_CONT 0xFFFFFFFDu      // continuation record of the previous token
@@ -96,7 +98,11 @@ struct FzStreamParams {
     uint32_t nwaves;           // waves per block = tiles per block
     uint32_t stride;           // dwords per lane of one Peq table word plane (odd, > max row)
     uint32_t nq;               // queries of this launch
-    uint32_t q_per_block;
+    uint32_t q_per_block;      // queries per group
+    uint32_t nitems;           // work items = ntiles * query groups, numbered group-major
+    uint32_t grid_blocks;      // persistent blocks to launch (the chip's CU count x blocks per CU)
+    uint32_t chunk;            // items a wave draws at a time (1..64)
+    uint32_t *work_counter;    // FZ_STREAM_QUEUES device counters FZ_STREAM_QPAD words apart, zero before the launch
     const uint8_t *row_of_sym; // [256] corpus symbol -> 4 * row, 0xFF = no query of this launch uses it
     const FzRec *recs;         // record stream
     const uint32_t *qrec;      // [nq] index of each query's header record

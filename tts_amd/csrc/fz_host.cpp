@@ -141,9 +141,14 @@ struct fz_corpus {
     uint64_t *d_keys = nullptr; size_t keys_cap = 0;
     uint32_t *d_cnt = nullptr; size_t cnt_cap = 0;
     uint8_t *d_score_tab[2] = {nullptr, nullptr};         // stream kernel: T[L][d] per rounding form
+    uint32_t *d_counters = nullptr;                       // stream kernel work-queue counters (64 launches x FZ_STREAM_QUEUES)
+    uint32_t counter_next = 0;
+    uint32_t n_cus = 256;
     uint16_t *d_ranks = nullptr; size_t ranks_cap = 0;    // fz_query_topk_pair: combined ranks, rank table
     uint16_t *d_rank_tab = nullptr; size_t rank_tab_cap = 0;
     bool use_stream = true;                               // FUZZYHIP_NO_STREAM=1 forces the general kernel
+    uint32_t stream_oversub = 1;                          // FUZZYHIP_STREAM_OVERSUB: persistent blocks per slot
+    uint32_t pipe_chunks = 1;                             // FUZZYHIP_CHUNKS: pieces of a large top-k batch
     uint32_t stream_waves = 16, stream_blocks = 8192;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
     std::vector<hipEvent_t> events;
     fz_timing timing{};
@@ -240,7 +245,7 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (View &v : c->views) free_view(v);
     for (void *p : {(void *)c->d_scores, (void *)c->d_qbuf, (void *)c->d_keys, (void *)c->d_cnt,
-                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1], (void *)c->d_ranks, (void *)c->d_rank_tab})
+                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1], (void *)c->d_ranks, (void *)c->d_rank_tab, (void *)c->d_counters})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -464,6 +469,14 @@ static int finish_create(fz_corpus *c)
     if (const char *e = getenv("FUZZYHIP_NO_STREAM")) c->use_stream = !(e[0] == '1');
     if (const char *e = getenv("FUZZYHIP_STREAM_WAVES")) c->stream_waves = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("FUZZYHIP_STREAM_BLOCKS")) c->stream_blocks = (uint32_t)std::max(1, atoi(e));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = (uint32_t)prop.multiProcessorCount;
+        HIP_TRY(hipMalloc((void **)&c->d_counters, 64 * FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(c->d_counters, 0, 64 * FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t)));
+    }
+    if (const char *e = getenv("FUZZYHIP_STREAM_OVERSUB")) c->stream_oversub = (uint32_t)std::min(16, std::max(1, atoi(e)));
+    if (const char *e = getenv("FUZZYHIP_CHUNKS")) c->pipe_chunks = (uint32_t)std::min(64, std::max(1, atoi(e)));
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     c->stream = c->own_stream;
@@ -1057,6 +1070,18 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
             const uint64_t bx = (nt + p.nwaves - 1) / p.nwaves;
             uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (c->stream_blocks + bx - 1) / bx));
             p.q_per_block = (uint32_t)((p.nq + by - 1) / by);
+            const uint64_t groups = (p.nq + p.q_per_block - 1) / p.q_per_block;
+            if ((uint64_t)nt * groups > 0xFFFFFF00ull) return fail(FZ_ERR_LIMIT, "too many work items in one launch");
+            p.nitems = (uint32_t)((uint64_t)nt * groups);
+            // as many persistent blocks as fit the chip at this LDS size; each drains the work queue
+            const size_t lds_b = fz_stream_lds_bytes(W, (int)stride, p.nwaves);
+            p.grid_blocks = c->n_cus * (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_b) * c->stream_oversub;
+            // small items (few queries per group) are drawn several at a time, but never so many that
+            // the chip's waves cannot all get a share
+            const uint64_t waves_total = (uint64_t)p.grid_blocks * p.nwaves;
+            p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1u, 32u / p.q_per_block), p.nitems / waves_total));
+            p.work_counter = c->d_counters + (size_t)(c->counter_next++ & 63u) * FZ_STREAM_QUEUES * FZ_STREAM_QPAD;
+            HIP_TRY(hipMemsetAsync(p.work_counter, 0, FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), st));
             p.row_of_sym = c->d_qbuf + o_rows;
             p.recs = reinterpret_cast<const FzRec *>(c->d_qbuf + o_rec);
             p.qrec = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_qrec);
@@ -1113,6 +1138,10 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     const uint64_t row_stride = v.npad;                            // in elements
     uint64_t rows_per_chunk = std::max<uint64_t>(1, c->ws_limit / (row_stride * esz));
     rows_per_chunk = std::min<uint64_t>(rows_per_chunk, nq);
+    // Large top-k batches go in `pipe_chunks` pieces: launches are asynchronous, so the host builds the
+    // query tables of piece i+1 while the GPU scores piece i.
+    if (topk && c->pipe_chunks > 1 && nq >= 256u * c->pipe_chunks)
+        rows_per_chunk = std::min<uint64_t>(rows_per_chunk, (nq + c->pipe_chunks - 1) / c->pipe_chunks);
     if ((rc = ensure(&c->d_scores, &c->scores_cap, (size_t)(rows_per_chunk * row_stride * esz))) != FZ_OK) return rc;
 
     std::vector<Tok> toks;

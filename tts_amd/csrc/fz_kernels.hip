@@ -448,10 +448,11 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
                                                   uint8_t *__restrict__ scores, const uint8_t *s_tab,
                                                   const uint8_t *col, const uint32_t (&cid)[FZ_STREAM_MAX_TOK],
                                                   const uint32_t (&Rm)[FZ_STREAM_MAX_TOK][W],
-                                                  const uint32_t (&psep)[W], uint32_t clen, uint32_t out_off)
+                                                  const uint32_t (&psep)[W], uint32_t clen, uint32_t out_off,
+                                                  uint32_t qgroup)
 {
     constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;
-    uint32_t q0 = blockIdx.y * p.q_per_block, q1 = q0 + p.q_per_block;
+    uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
     uint32_t ri = p.qrec[q0];
     FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with two padding records
@@ -571,68 +572,108 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
     if (tid < 64u) reinterpret_cast<uint32_t *>(s_row)[tid] = reinterpret_cast<const uint32_t *>(p.row_of_sym)[tid];
     __syncthreads();                                                     // the only block-wide barrier
 
-    const uint32_t tix = blockIdx.x * p.nwaves + wave;
-    if (tix >= p.ntiles) return;
-    const uint32_t tile = p.tile_list[tix];
-    const FzTile td = p.tiles[tile];
-    const uint32_t ndw = td.ndw, ntok = td.ntok;
+    // ---- work queues: every wave takes (query group, tile) items until none is left ---------------
+    // A wave that finishes early takes the next item instead of idling until its block is done: the
+    // LDS column is private to the wave, so no block-wide barrier is needed after the table load
+    // above.  Items are numbered group-major and dealt round-robin to FZ_STREAM_QUEUES queues, each
+    // behind its own counter (one counter for the whole chip serialises at ~12 ns per draw); a wave
+    // draws `chunk` positions at a time from its home queue and moves on to the next queue when that
+    // one is empty.  Exit: counters only grow, and a wave leaves when a scan finds every queue drained.
     uint8_t *col = s_peq + wave * ((uint32_t)W * PLANE) + lane * ((uint32_t)STRIDE * 4u);   // this lane's column
-
-    // ---- candidate side, once per tile ----------------------------------------------------------
-#pragma unroll
-    for (int w = 0; w < W; ++w)
-        for (uint32_t r = 0; r < (uint32_t)STRIDE; ++r) *reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r * 4u) = 0u;
-
-    uint32_t cid[FZ_STREAM_MAX_TOK], Rm[FZ_STREAM_MAX_TOK][W], prev_end = 0u;
-#pragma unroll
-    for (int i = 0; i < (int)FZ_STREAM_MAX_TOK; ++i) {
-        uint32_t end = prev_end;
-        cid[i] = FZ_TOK_NONE;
-        if ((uint32_t)i < ntok) {
-            if (MODE == FZ_MODE_TOKEN_SET) cid[i] = p.tokid[td.toff + (uint32_t)i * 64u + lane];
-            end = p.tokend[td.toff + (uint32_t)i * 64u + lane];
+    uint32_t queue = (blockIdx.x + wave) % FZ_STREAM_QUEUES;
+    uint32_t pos = 0u, pos_end = 0u;                     // positions [pos, pos_end) of `queue` are this wave's
+    for (;;) {
+        if (pos >= pos_end) {
+            // queue q holds the items q, q + QUEUES, q + 2*QUEUES, ...: all queues walk the query groups
+            // in the same order, so the chip works on the same records at the same time (scalar cache)
+            const uint32_t q_len = queue < p.nitems ? (p.nitems - queue + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES : 0u;
+            // counters sit FZ_STREAM_QPAD words apart (one cache line each); a plain load first, so
+            // that a drained queue costs no atomic
+            uint32_t *cnt = p.work_counter + queue * FZ_STREAM_QPAD;
+            uint32_t got = 0xFFFFFFFFu;
+            if (lane == 0u && q_len != 0u && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_len)
+                got = atomicAdd(cnt, p.chunk);
+            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            if (got >= q_len) {
+                // this queue is drained: lane l looks at queue l, the wave moves to the next queue that
+                // still has positions, or leaves when there is none (one load round trip, not QUEUES)
+                bool open = false;
+                if (lane < FZ_STREAM_QUEUES && lane < p.nitems) {
+                    const uint32_t len_l = (p.nitems - lane + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES;
+                    open = __hip_atomic_load(p.work_counter + lane * FZ_STREAM_QPAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len_l;
+                }
+                const uint64_t mask = __ballot(open);
+                if (mask == 0ull) break;
+                const uint64_t ahead = mask >> queue;                    // queues at or after this one
+                queue = ahead != 0ull ? queue + (uint32_t)__builtin_ctzll(ahead) : (uint32_t)__builtin_ctzll(mask);
+                continue;
+            }
+            pos = got;
+            pos_end = got + p.chunk < q_len ? got + p.chunk : q_len;
         }
-        const uint64_t hi = end >= 64u ? ~0ull : ((1ull << end) - 1ull);
-        const uint64_t lo = prev_end >= 64u ? ~0ull : ((1ull << prev_end) - 1ull);
-        const uint64_t r = hi & ~lo;                                     // pattern positions of token i
-        Rm[i][0] = (uint32_t)r;
-        if (W == 2) Rm[i][W - 1] = (uint32_t)(r >> 32);
-        prev_end = end;
-    }
-    const uint32_t clen = prev_end;
+        const uint32_t item = queue + pos * FZ_STREAM_QUEUES;
+        ++pos;
+        const uint32_t qgroup = item / p.ntiles, tix = item - qgroup * p.ntiles;
+        const uint32_t tile = p.tile_list[tix];
+        const FzTile td = p.tiles[tile];
+        const uint32_t ndw = td.ndw, ntok = td.ntok;
 
-    uint32_t psep[W];
+        // ---- candidate side, once per item -------------------------------------------------------
 #pragma unroll
-    for (int w = 0; w < W; ++w) psep[w] = 0u;
+        for (int w = 0; w < W; ++w)
+            for (uint32_t r = 0; r < (uint32_t)STRIDE; ++r) *reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r * 4u) = 0u;
+
+        uint32_t cid[FZ_STREAM_MAX_TOK], Rm[FZ_STREAM_MAX_TOK][W], prev_end = 0u;
 #pragma unroll
-    for (int d = 0; d < 8 * W; ++d) {
-        if ((uint32_t)d < ndw) {
-            const uint32_t cw = p.sym[td.coff + (uint32_t)d * 64u + lane];
+        for (int i = 0; i < (int)FZ_STREAM_MAX_TOK; ++i) {
+            uint32_t end = prev_end;
+            cid[i] = FZ_TOK_NONE;
+            if ((uint32_t)i < ntok) {
+                if (MODE == FZ_MODE_TOKEN_SET) cid[i] = p.tokid[td.toff + (uint32_t)i * 64u + lane];
+                end = p.tokend[td.toff + (uint32_t)i * 64u + lane];
+            }
+            const uint64_t hi = end >= 64u ? ~0ull : ((1ull << end) - 1ull);
+            const uint64_t lo = prev_end >= 64u ? ~0ull : ((1ull << prev_end) - 1ull);
+            const uint64_t r = hi & ~lo;                                     // pattern positions of token i
+            Rm[i][0] = (uint32_t)r;
+            if (W == 2) Rm[i][W - 1] = (uint32_t)(r >> 32);
+            prev_end = end;
+        }
+        const uint32_t clen = prev_end;
+
+        uint32_t psep[W];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t s = (cw >> (8 * k)) & 0xFFu;
-                const uint32_t bit = 1u << ((d * 4 + k) & 31);
-                const int w = (d * 4 + k) >> 5;
-                if (MODE == FZ_MODE_TOKEN_SET && s == FZ_SYM_SPACE) {
-                    psep[w] |= bit;
-                } else {
-                    const uint32_t r4 = s_row[s];                        // 0xFF: no query uses this symbol
-                    if (r4 != 0xFFu)
-                        __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r4), bit,
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int w = 0; w < W; ++w) psep[w] = 0u;
+#pragma unroll
+        for (int d = 0; d < 8 * W; ++d) {
+            if ((uint32_t)d < ndw) {
+                const uint32_t cw = p.sym[td.coff + (uint32_t)d * 64u + lane];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t s = (cw >> (8 * k)) & 0xFFu;
+                    const uint32_t bit = 1u << ((d * 4 + k) & 31);
+                    const int w = (d * 4 + k) >> 5;
+                    if (MODE == FZ_MODE_TOKEN_SET && s == FZ_SYM_SPACE) {
+                        psep[w] |= bit;
+                    } else {
+                        const uint32_t r4 = s_row[s];                        // 0xFF: no query uses this symbol
+                        if (r4 != 0xFFu)
+                            __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r4), bit,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }
-    }
 
-    // ---- the queries of this block: a stream of wave-uniform records (scalar loads) ----------------
-    const uint32_t out_off = tile * 64u + lane;
-    if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
-    else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
-    else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
-    else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
-    else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
-    else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off);
+        // ---- the queries of this group: a stream of wave-uniform records (scalar loads) ------------
+        const uint32_t out_off = tile * 64u + lane;
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
+        else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
+    }
 }
 
 size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves)
@@ -649,7 +690,9 @@ static hipError_t launch_stream3(const FzStreamParams &p, hipStream_t st)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    dim3 grid((p.ntiles + p.nwaves - 1u) / p.nwaves, (p.nq + p.q_per_block - 1u) / p.q_per_block);
+    // persistent blocks (one per CU at full LDS) drain the (query group, tile) work queue
+    const uint64_t blocks_needed = ((uint64_t)p.nitems + p.nwaves - 1u) / p.nwaves;
+    dim3 grid((uint32_t)(blocks_needed < p.grid_blocks ? blocks_needed : p.grid_blocks));
     hipLaunchKernelGGL((fz_score_stream<W, MODE, STRIDE>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
     return hipGetLastError();
 }
@@ -665,7 +708,8 @@ static hipError_t launch_stream2(const FzStreamParams &p, hipStream_t st)
 hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_t st)
 {
     if (p.nq == 0u || p.ntiles == 0u) return hipSuccess;
-    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u) return hipErrorInvalidValue;
+    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u) return hipErrorInvalidValue;
+    if ((uint64_t)p.ntiles * ((p.nq + p.q_per_block - 1u) / p.q_per_block) != p.nitems) return hipErrorInvalidValue;
     if (W == 1 && mode == FZ_MODE_TOKEN_SET) return launch_stream2<1, FZ_MODE_TOKEN_SET>(p, st);
     if (W == 2 && mode == FZ_MODE_TOKEN_SET) return launch_stream2<2, FZ_MODE_TOKEN_SET>(p, st);
     if (W == 1 && mode == FZ_MODE_RATIO) return launch_stream2<1, FZ_MODE_RATIO>(p, st);
