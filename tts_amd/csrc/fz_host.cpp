@@ -1054,7 +1054,9 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
         c->timing.score_launches++;
     }
     if (!b.qrec.empty()) {
-        const uint32_t stride = b.nrows <= 41u ? 41u : 65u;
+        // odd strides keep the 64 lane columns on distinct banks; the smallest one that holds the rows of
+        // this launch leaves room for the most waves (37: a-z, 0-9 and one spare)
+        const uint32_t stride = b.nrows <= 37u ? 37u : (b.nrows <= 41u ? 41u : 65u);
         for (int W = 1; W <= 2; ++W) {
             const uint32_t nt = W == 1 ? v.n_s1 : v.n_s2;
             if (nt == 0) continue;

@@ -700,6 +700,7 @@ static hipError_t launch_stream3(const FzStreamParams &p, hipStream_t st)
 template <int W, int MODE>
 static hipError_t launch_stream2(const FzStreamParams &p, hipStream_t st)
 {
+    if (p.stride == 37u) return launch_stream3<W, MODE, 37>(p, st);
     if (p.stride == 41u) return launch_stream3<W, MODE, 41>(p, st);
     if (p.stride == 65u) return launch_stream3<W, MODE, 65>(p, st);
     return hipErrorInvalidValue;
