@@ -196,6 +196,13 @@ int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, ui
  *   kind 1: uniform-cost Levenshtein by the Myers/Hyyro Pv/Mv bit-vector recurrence; this is
  *           AdvancedFuzzyMatcher.levenshtein_distance of reference app.py:296-317 once the host has
  *           applied its normalize_text (app.py:271-273) to both sides
+ *   kind 2: number of the candidate's distinct whitespace-separated tokens that the query also has.
+ *           With each string replaced by its distinct character n-grams this is the |A & B| of
+ *           AdvancedFuzzyMatcher.jaccard_similarity (app.py:282-293)
+ *   kind 3: 1 if the query occurs in the candidate as a contiguous substring, else 0 (bit-parallel
+ *           Shift-And): `query_norm in target_norm` of substring_match_score (app.py:337-345) and,
+ *           with a sentinel in front of both sides, the startswith tests of prefix_match_score
+ *           (app.py:320-334)
  */
 int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                     int kind, uint16_t *out_dist);

@@ -318,3 +318,142 @@ def weighted_find_best_matches(items: List[str], query: str, threshold: float = 
             matches.append((original_item, final_score))
     matches.sort(key=lambda x: x[1], reverse=True)
     return matches[:top_n]
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's AdvancedFuzzyMatcher (app.py:130-460), per candidate, statement for statement.
+# Pure Python + difflib (stdlib) + the C Levenshtein DP above; tiny inputs only.
+# ----------------------------------------------------------------------------------------------
+import re as _re
+from difflib import SequenceMatcher as _SM
+
+ADV_CONFIG = {'threshold': 0.7, 'top_n': 5, 'prefix_weight': 1.0, 'substring_weight': 0.9,
+              'sequence_weight': 0.85, 'jaccard_weight': 0.8, 'levenshtein_weight': 0.8,
+              'unit_conversion_weight': 0.95}                                   # app.py:253-262
+ADV_UNITS = {                                                                   # app.py:116-128
+    'ml': {'ml': 1, 'l': 0.001, 'lt': 0.001, 'ltr': 0.001},
+    'l': {'ml': 1000, 'l': 1, 'lt': 1, 'ltr': 1},
+    'lt': {'ml': 1000, 'l': 1, 'lt': 1, 'ltr': 1},
+    'ltr': {'ml': 1000, 'l': 1, 'lt': 1, 'ltr': 1},
+    'g': {'g': 1, 'kg': 0.001},
+    'kg': {'g': 1000, 'kg': 1},
+    'pcs': {'pcs': 1, 'pc': 1, 'piece': 1, 'pieces': 1},
+    'pc': {'pcs': 1, 'pc': 1, 'piece': 1, 'pieces': 1},
+}
+
+
+def adv_normalize_text(text):                        # app.py:271-273
+    return _re.sub(r'[^a-z0-9]', '', text.lower())
+
+
+def _adv_extract(text):                              # app.py:137-151
+    m = _re.search(r'(\d+\.?\d*)\s*([a-zA-Z]+)', text.lower())
+    if m:
+        try:
+            return float(m.group(1)), m.group(2).lower()
+        except (ValueError, AttributeError):
+            return None
+    return None
+
+
+def _adv_norm_unit(unit):                            # app.py:154-167
+    u = unit.lower()
+    if u in ADV_UNITS:
+        return u
+    for std, conv in ADV_UNITS.items():
+        if u in conv:
+            return std
+    return None
+
+
+def _adv_equivalent(t1, t2, tol=0.01):               # app.py:170-220
+    a, b = _adv_extract(t1), _adv_extract(t2)
+    if not a or not b:
+        return False
+    (q1, u1), (q2, u2) = a, b
+    n1, n2 = _adv_norm_unit(u1), _adv_norm_unit(u2)
+    if not n1 or not n2:
+        return False
+    if n1 not in ADV_UNITS or n2 not in ADV_UNITS[n1]:
+        return False
+    converted = q1 * ADV_UNITS[n1][n2]
+    return abs(converted - q2) <= (q2 * tol)
+
+
+def _adv_unit_score(query, target):                  # app.py:348-376
+    if not _adv_extract(query) or not _adv_extract(target):
+        return 0.0
+    if _adv_equivalent(query, target):
+        a = _re.sub(r'\d+\.?\d*\s*[a-zA-Z]+', '', query).strip()
+        b = _re.sub(r'\d+\.?\d*\s*[a-zA-Z]+', '', target).strip()
+        if a.lower() == b.lower():
+            return 1.0
+        sim = _SM(None, adv_normalize_text(a), adv_normalize_text(b)).ratio()
+        return sim if sim > 0.6 else 0.0
+    return 0.0
+
+
+def _adv_jaccard(s1, s2, n):                         # app.py:276-293
+    a, b = adv_normalize_text(s1), adv_normalize_text(s2)
+    g1 = set(a[i:i + n] for i in range(len(a) - n + 1))
+    g2 = set(b[i:i + n] for i in range(len(b) - n + 1))
+    if not g1 or not g2:
+        return 0.0
+    inter, union = len(g1 & g2), len(g1 | g2)
+    return inter / union if union > 0 else 0.0
+
+
+def _adv_prefix(query, target):                      # app.py:320-334
+    qn, tn = adv_normalize_text(query), adv_normalize_text(target)
+    if tn.startswith(qn):
+        return 1.0
+    for word in target.lower().split():
+        if adv_normalize_text(word).startswith(qn):
+            return 0.9
+    return 0.0
+
+
+def _adv_substring(query, target):                   # app.py:337-345
+    qn, tn = adv_normalize_text(query), adv_normalize_text(target)
+    if qn in tn:
+        return len(qn) / len(tn)
+    return 0.0
+
+
+def advanced_fuzzy_search(query, candidates, threshold=None, top_n=None):
+    """app.py:378-460"""
+    if threshold is None:
+        threshold = ADV_CONFIG['threshold']
+    if top_n is None:
+        top_n = ADV_CONFIG['top_n']
+    if not query or not candidates:
+        return []
+    results = []
+    for candidate in candidates:
+        if query.lower() == candidate.lower():
+            results.append({'value': candidate, 'score': 1.0, 'method': 'exact'})
+            continue
+        unit_score = _adv_unit_score(query, candidate)
+        if unit_score > 0:
+            results.append({'value': candidate, 'score': unit_score * ADV_CONFIG['unit_conversion_weight'],
+                            'method': 'unit_conversion'})
+            continue
+        prefix_score = _adv_prefix(query, candidate)
+        substring_score = _adv_substring(query, candidate)
+        qn, cn = adv_normalize_text(query), adv_normalize_text(candidate)
+        sequence_score = _SM(None, qn, cn).ratio()
+        j2 = _adv_jaccard(query, candidate, 2)
+        j3 = _adv_jaccard(query, candidate, 3)
+        lev_distance = levenshtein(qn, cn)           # app.py:296-317: Wagner-Fischer on the normalised strings
+        max_len = max(len(qn), len(cn))
+        lev_score = 1 - (lev_distance / max_len) if max_len > 0 else 0
+        final_score = max(prefix_score * ADV_CONFIG['prefix_weight'], substring_score * ADV_CONFIG['substring_weight'],
+                          sequence_score * ADV_CONFIG['sequence_weight'], j2 * ADV_CONFIG['jaccard_weight'],
+                          j3 * 0.75, lev_score * ADV_CONFIG['levenshtein_weight'])
+        method_scores = {'prefix': prefix_score, 'substring': substring_score, 'sequence': sequence_score,
+                         'jaccard': max(j2, j3), 'levenshtein': lev_score}
+        best_method = max(method_scores, key=method_scores.get)
+        if final_score >= threshold:
+            results.append({'value': candidate, 'score': final_score, 'method': best_method})
+    results.sort(key=lambda x: x['score'], reverse=True)
+    return results[:top_n]

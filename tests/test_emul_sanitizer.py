@@ -253,3 +253,22 @@ def test_save_load_roundtrip(oracle, runner, tmp_path):
     wide, vocab = _wide_corpus(120, 53)
     got = _run(runner, tmp_path, 4, 0, wide, [wide[3], vocab[2]])
     assert (got == _oracle_scores(oracle, oracle.TOKEN_SET, [wide[3], vocab[2]], wide)).all()
+
+
+def test_common_tokens_and_substring(oracle, runner, tmp_path):
+    """fz_distance_all kind 2 (set intersection size) and kind 3 (Shift-And substring search)"""
+    import random
+    rnd = random.Random(61)
+    toks = ["ab", "bc", "cd", "de", "ef", "zz", "q1", "w2", "abc", "bcd"]
+    cand = [" ".join(rnd.choice(toks) for _ in range(rnd.randint(0, 12))) for _ in range(150)] + ["", "ab ab ab"]
+    queries = ["ab bc cd", "", "zz", "q1 q1 w2 nope", " ".join(toks)]
+    got = _run(runner, tmp_path, 1, 2, cand, queries)
+    for qi, q in enumerate(queries):
+        for i, s in enumerate(cand):
+            assert int(got[qi, i]) == len(set(q.split()) & set(s.split())), (q, s)
+    text = ["".join(rnd.choice("abc") for _ in range(rnd.randint(0, 90))) for _ in range(150)] + ["", "abc", "\x01abc"]
+    pats = ["", "a", "abc", "cab", "abca" * 9, "\x01ab", "c" * 33, "ab" * 40, "x"]
+    got = _run(runner, tmp_path, 1, 3, text, pats)
+    for qi, q in enumerate(pats):
+        for i, s in enumerate(text):
+            assert int(got[qi, i]) == (1 if q in s else 0), (q, s)

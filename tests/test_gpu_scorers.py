@@ -192,3 +192,51 @@ def test_weighted_fuzzysearch_dropin(oracle):
     for q in queries[:6]:
         assert lo.find_best_matches(q, "product") == oracle.weighted_find_best_matches(products, q, 0.30, 0.98, 25), q
     lo.close()
+
+
+def test_advanced_fuzzy_matcher_dropin(oracle):
+    """AdvancedFuzzyMatcher.fuzzy_search (reference app.py:378-460): exact, unit conversion, prefix,
+    substring, SequenceMatcher, bigram/trigram Jaccard and Levenshtein strategies; same dicts out."""
+    from tts_amd.advanced_matcher import AdvancedFuzzyMatcher
+    rnd = random.Random(101)
+    brands = ["Coke", "Coke Zero", "Sprite", "Fanta Orange", "Mirinda", "Aquafina", "Mountain Dew", "7UP", "Pepsi Max"]
+    sizes = ["330ml", "1.5L", "1500ml", "2 kg", "2000g", "500 ML", "1L", "1 ltr", "24 pcs", "24 pieces", "0.33l", ""]
+    packs = ["1x24", "NP", "Sleek Can", "PET", "(Glass)", "Promo-Pack", ""]
+    candidates = []
+    for _ in range(2500):
+        parts = [rnd.choice(brands), rnd.choice(sizes), rnd.choice(packs)]
+        rnd.shuffle(parts)
+        candidates.append(" ".join(p for p in parts if p))
+    candidates += ["", "&&", "coke", "COKE", "Sprite Zero Sugar 330ml", "x" * 250 + " long tail name " + "y" * 30]
+    queries = ["coke", "Coke 1.5L", "coke 1500ml", "sprit", "fanta orng 330", "mountan dew 2kg", "7up 24 pcs", "aquafina 0.5l",
+               "pepsi", "zero", "Sprite Zero Sugar 330 ml", "mirnda pet", "1x24", "qqqq", "coke zero 330ml sleek can"]
+    for q in queries:
+        got = AdvancedFuzzyMatcher.fuzzy_search(q, candidates)
+        exp = oracle.advanced_fuzzy_search(q, candidates)
+        assert got == exp, (q, got[:3], exp[:3])
+    for thr, top in ((0.3, 40), (0.9, 3), (0.55, 12)):
+        for q in queries[:8]:
+            got = AdvancedFuzzyMatcher.fuzzy_search(q, candidates, threshold=thr, top_n=top)
+            assert got == oracle.advanced_fuzzy_search(q, candidates, thr, top), (thr, top, q)
+    assert AdvancedFuzzyMatcher.fuzzy_search("", candidates) == [] and AdvancedFuzzyMatcher.fuzzy_search("coke", []) == []
+    AdvancedFuzzyMatcher.clear_cache()
+
+
+def test_common_tokens_and_substring_kinds():
+    """fz_distance_all kind 2 (|A & B| over distinct tokens) and kind 3 (substring search), definitional checks"""
+    rnd = random.Random(111)
+    toks = ["ab", "bc", "cd", "de", "ef", "zz", "q1", "w2", "abc", "bcd"] + ["t%d" % i for i in range(40)]
+    cand = [" ".join(rnd.choice(toks) for _ in range(rnd.randint(0, 30))) for _ in range(1500)] + ["", "ab ab ab"]
+    queries = ["ab bc cd", "", "zz", "q1 q1 w2 nope", " ".join(toks)]
+    with Corpus.from_prepared(cand) as c:
+        got = c.distance_all(queries, 2)
+    for qi, q in enumerate(queries):
+        for i, s in enumerate(cand):
+            assert int(got[qi, i]) == len(set(q.split()) & set(s.split())), (q, s)
+    text = ["".join(rnd.choice("abc") for _ in range(rnd.randint(0, 200))) for _ in range(1500)] + ["", "abc", "\x01abc"]
+    pats = ["", "a", "abc", "cab", "abca" * 9, "\x01ab", "c" * 33, "ab" * 40, "x", "abcabc" * 30]
+    with Corpus.from_prepared(text) as c:
+        got = c.distance_all(pats, 3)
+    for qi, q in enumerate(pats):
+        for i, s in enumerate(text):
+            assert int(got[qi, i]) == (1 if q in s else 0), (q, s)

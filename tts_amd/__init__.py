@@ -4,5 +4,7 @@ handle-level API over ``libfuzzyhip.so``."""
 from .config import FUZZY_SEARCH_THRESHOLD_FLOAT, TOP_N_MATCHES_INT
 from .corpus import Corpus, distance_batch, merge_topk
 from .fuzzy_search import FuzzySearch
+from .weighted_search import WeightedFuzzySearch
+from .advanced_matcher import AdvancedFuzzyMatcher
 
-__all__ = ["FuzzySearch", "Corpus", "merge_topk", "distance_batch", "TOP_N_MATCHES_INT", "FUZZY_SEARCH_THRESHOLD_FLOAT"]
+__all__ = ["FuzzySearch", "WeightedFuzzySearch", "AdvancedFuzzyMatcher", "Corpus", "merge_topk", "distance_batch", "TOP_N_MATCHES_INT", "FUZZY_SEARCH_THRESHOLD_FLOAT"]

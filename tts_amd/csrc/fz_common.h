@@ -12,6 +12,8 @@
 #define FZ_MODE_INDEL 2
 #define FZ_MODE_LEV 3
 #define FZ_MODE_PARTIAL 4
+#define FZ_MODE_NHITS 5
+#define FZ_MODE_FIND 6
 #define FZ_IDX_BITS 40
 #define FZ_IDX_MASK ((1ull << FZ_IDX_BITS) - 1ull)
 

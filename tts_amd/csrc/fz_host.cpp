@@ -1268,10 +1268,11 @@ extern "C" int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t 
 extern "C" int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                                int kind, uint16_t *out_dist)
 {
-    if (kind != 0 && kind != 1) return fail(FZ_ERR_INVALID, "kind must be 0 (InDel) or 1 (Levenshtein)");
+    if (kind < 0 || kind > 3) return fail(FZ_ERR_INVALID, "kind must be 0 (InDel), 1 (Levenshtein), 2 (common tokens) or 3 (substring)");
     if (nq && c && c->n && !out_dist) return fail(FZ_ERR_INVALID, "null output buffer");
     RunOut o; o.dists = out_dist;
-    return run_queries(c, q_cps, q_offs, nq, VIEW_RAW, kind == 0 ? FZ_MODE_INDEL : FZ_MODE_LEV,
+    static const int kModes[4] = {FZ_MODE_INDEL, FZ_MODE_LEV, FZ_MODE_NHITS, FZ_MODE_FIND};
+    return run_queries(c, q_cps, q_offs, nq, kind == 2 ? VIEW_SET : VIEW_RAW, kModes[kind],
                        FzTies{0, 0}, 0, 0, RUN_DIST_ALL, o);
 }
 

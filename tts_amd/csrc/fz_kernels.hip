@@ -88,6 +88,8 @@ __device__ __forceinline__ void fz_clear_bits(uint32_t *row, uint32_t s, uint32_
 //       FZ_MODE_RATIO      plain InDel ratio of pattern vs text, thefuzz ratio()/token_sort (u8)
 //       FZ_MODE_INDEL      raw InDel distance (u16)
 //       FZ_MODE_LEV        raw uniform-cost Levenshtein distance, Myers/Hyyro Pv/Mv recurrence (u16)
+//       FZ_MODE_NHITS      number of candidate tokens that are query tokens (u16): set intersection size
+//       FZ_MODE_FIND       1 if the pattern occurs in the text as a substring, else 0 (u16); Shift-And
 // WIDE: the corpus has more than 254 distinct code points, so its symbols are 16 bits (two per
 //       dword) and the Peq table is indirect: a u16 map [alphabet] -> row of a table that only holds
 //       the symbols of THIS query (row 0 = all zero = every other symbol), both in LDS.
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 
         // ---- token intersection: which candidate tokens are query tokens ---------------------
         uint32_t sect1 = 0u, nhits = 0u, prev_end = 0u;
-        if (MODE != FZ_MODE_TOKEN_SET) {
+        if (MODE != FZ_MODE_TOKEN_SET && MODE != FZ_MODE_NHITS) {
             // plain views carry one slot per candidate: its length
             if (td.ntok) prev_end = p.tokend[td.toff + lane];
         } else
@@ -169,7 +171,40 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
         }
         const uint32_t clen = prev_end;                       // pad slots carry end = length
 
+        if (MODE == FZ_MODE_NHITS) {
+            reinterpret_cast<uint16_t *>(p.scores)[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint16_t)nhits;
+            continue;
+        }
+
         const uint32_t *symp = p.sym + td.coff + lane;
+        if (MODE == FZ_MODE_FIND) {
+            // ---- Shift-And: bit j of D = "pattern[0..j] ends here"; a set bit m-1 is an occurrence --
+            uint32_t D[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) D[w] = 0u;
+            uint32_t found = q.m == 0u ? 1u : 0u;                 // '' in t is True
+            const uint32_t lastw = q.m ? (q.m - 1u) >> 5 : 0u, lastb = q.m ? (q.m - 1u) & 31u : 0u;
+            for (uint32_t d = 0; d < td.ndw; ++d) {
+                const uint32_t cw = symp[d * 64u];
+#pragma unroll
+                for (int k = 0; k < SY::SPD; ++k) {
+                    const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;   // padding symbols clear D: no false hit
+                    const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
+                    uint32_t carry = 1u;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const uint32_t nxt = D[w] >> 31;
+                        D[w] = ((D[w] << 1) | carry) & row[w];
+                        carry = nxt;
+                    }
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        if ((uint32_t)w == lastw) found |= (D[w] >> lastb) & 1u;
+                }
+            }
+            reinterpret_cast<uint16_t *>(p.scores)[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint16_t)found;
+            continue;
+        }
         if (MODE == FZ_MODE_LEV) {
             // ---- Myers/Hyyro bit-vector Levenshtein; the W words act as one big integer --------
             uint32_t Pv[W], Mv[W];
@@ -1186,6 +1221,8 @@ static hipError_t launch_general(int mode, const FzScoreParams &p, dim3 grid, si
     case FZ_MODE_RATIO: return launch_general2<W, FZ_MODE_RATIO>(p, grid, lds, st);
     case FZ_MODE_INDEL: return launch_general2<W, FZ_MODE_INDEL>(p, grid, lds, st);
     case FZ_MODE_LEV: return launch_general2<W, FZ_MODE_LEV>(p, grid, lds, st);
+    case FZ_MODE_NHITS: return launch_general2<W, FZ_MODE_NHITS>(p, grid, lds, st);
+    case FZ_MODE_FIND: return launch_general2<W, FZ_MODE_FIND>(p, grid, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
