@@ -729,6 +729,11 @@ struct QueryBatch {
     std::vector<uint32_t> qrec;
     uint8_t row_of_sym[256];
     uint32_t nrows = 0;
+    struct Trip { uint32_t id, pos, len1; };
+    std::u32string s_pat;                // scratch of prepare_query, reused from query to query
+    std::vector<Trip> s_trips;
+    std::vector<uint8_t> s_text;
+    std::vector<uint32_t> s_tok_first, s_ids;
     QueryBatch() { memset(row_of_sym, 0xFF, sizeof row_of_sym); }
 };
 
@@ -799,11 +804,14 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
                          QueryBatch &b, std::vector<Tok> &toks)
 {
     const View &v = c->views[kind];
-    std::u32string pat;
-    struct Trip { uint32_t id, pos, len1; };
-    std::vector<Trip> trips;
-    std::vector<uint8_t> text;                 // stream kernel: text symbols, separators left out
-    std::vector<uint32_t> tok_first{0u}, ids;
+    // per-query scratch lives in the batch: no heap traffic per query
+    std::u32string &pat = b.s_pat;
+    std::vector<QueryBatch::Trip> &trips = b.s_trips;
+    std::vector<uint8_t> &text = b.s_text;     // stream kernel: text symbols, separators left out
+    std::vector<uint32_t> &tok_first = b.s_tok_first, &ids = b.s_ids;
+    pat.clear(); trips.clear(); text.clear(); ids.clear();
+    tok_first.assign(1, 0u);
+    using Trip = QueryBatch::Trip;
     uint32_t ntok = 0;
     auto sym_of = [&](uint32_t cp) -> uint32_t { return cp < 0x110000u ? v.sym_of_cp[cp] : 0u; };
     if (kind == VIEW_RAW) {
@@ -975,12 +983,14 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
     // the score table covers L < 128; a stream tile holds at most 64 symbols.  token_set looks up
     // L = m + clen - 2, ratio L = m + clen.
     b.stream_max_m = kmode == FZ_MODE_TOKEN_SET ? (FZ_STREAM_TAB + 1u - 64u) : (FZ_STREAM_TAB - 1u - 64u);
+    if (b.allow_stream) { b.recs.reserve((size_t)rows * 8 + 2); b.qrec.reserve(rows); }
     for (uint32_t r = 0; r < rows; ++r) {
         const uint64_t qi = q0 + r;
         if (q_offs[qi + 1] < q_offs[qi]) return fail(FZ_ERR_INVALID, "query offsets not monotone at %llu", (unsigned long long)qi);
         rc = prepare_query(c, view_kind, q_cps + q_offs[qi], q_offs[qi + 1] - q_offs[qi], r, b, toks);
         if (rc != FZ_OK) return rc;
     }
+    const auto t_prep = std::chrono::steady_clock::now();
     b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches two records ahead
     b.recs.push_back(FzRec{0, 0, 0, 0});
     // one device blob: [FzQuery list][peq][tok_id][tok_pos][tok_len1][stream records][qrec][rows]
@@ -1015,6 +1025,13 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
     if ((rc = ensure(&c->d_qbuf, &c->qbuf_cap, blob.size())) != FZ_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_qbuf, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));          // blob is pageable host memory owned by this scope
+    if (getenv("FUZZYHIP_PREP_DEBUG")) {
+        const auto t_up = std::chrono::steady_clock::now();
+        fprintf(stderr, "[prep dbg] %u queries: tables %.3f ms, blob %.3f ms (%zu bytes), upload+sync %.3f ms\n", rows,
+                std::chrono::duration<double, std::milli>(t_prep - t0).count(),
+                c->timing.host_prep_ms - std::chrono::duration<double, std::milli>(t_prep - t0).count(),
+                blob.size(), std::chrono::duration<double, std::milli>(t_up - t0).count() - c->timing.host_prep_ms);
+    }
 
     if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, st));
     for (auto &l : launches) {
