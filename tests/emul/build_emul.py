@@ -3,7 +3,8 @@ with g++ -fsanitize=address,undefined over the HIP stand-in of hip_emul.h.  TEST
 ONLY (GPU AddressSanitizer is not available on the MI355X pool); the product never loads it.
 
 The only textual changes made to the kernel source on its way to g++ are the two constructs that
-have no host spelling: the dynamic-LDS declaration and the "v" (VGPR) inline-asm constraint."""
+have no host spelling: the dynamic-LDS declaration, the "v" (VGPR) inline-asm constraint and the
+one-instruction SDWA byte add (rewritten as the C expression it computes)."""
 from __future__ import annotations
 
 import os
@@ -19,8 +20,15 @@ BIN = os.path.join(OUT, "emul_runner")
 _DYN_LDS = re.compile(r"extern\s+__shared__\s+(?:__align__\(\d+\)\s+)?(\w+)\s+(\w+)\[\];")
 
 
+_SDWA_ADD = re.compile(r'asm\("v_add_u32_sdwa %0, %1, %2 [^"]*src0_sel:BYTE_(\d)[^"]*" : "=v"\((\w+)\) : "s"\((\w+)\), "v"\((\w+)\)\);')
+
+
 def _translate(src: str) -> str:
     src = _DYN_LDS.sub(r"\1 *\2 = reinterpret_cast<\1 *>(emul::dyn_lds());", src)
+    # v_add_u32_sdwa with a byte select on src0: dst = src1 + byte K of src0
+    src = _SDWA_ADD.sub(r"\2 = \4 + ((\3 >> (8 * \1)) & 0xFFu);", src)
+    # a line that ends in "// EMUL: <statement>" is replaced by that statement
+    src = re.sub(r"^[^\n]*// EMUL: ([^\n]*)$", r"\1", src, flags=re.M)
     return src.replace('"+v"', '"+r"')
 
 

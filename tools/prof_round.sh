@@ -1,0 +1,16 @@
+set -e
+TAG=${1:-r01x}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out
+timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $O/${TAG}_tests.log 2>&1
+timeout -k 10 300 python bench.py --steps 5 --warmup 1 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-reps 0"
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -o ${TAG} -- $B > $O/${TAG}_trace.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o p -- $B > $O/${TAG}_pmc_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o p -- $B > $O/${TAG}_pmc_write.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/${TAG}_pmc_sq1 -o p -- $B > $O/${TAG}_pmc_sq1.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU -d $O/${TAG}_pmc_sq2 -o p -- $B > $O/${TAG}_pmc_sq2.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $O/${TAG}_pmc_grbm -o p -- $B > $O/${TAG}_pmc_grbm.log 2>&1
+find $O -name "*.db" -newer $O/${TAG}_tests.log | sort > $O/${TAG}_dbs.txt
+python tools/rocpd_summary.py $(cat $O/${TAG}_dbs.txt) > $O/${TAG}_summary.txt 2>&1
+echo done

@@ -459,6 +459,32 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
 //   score: T[L][d] = the rounded ratio, a 16 KiB table the host fills with the scorer's own
 //     rounding (fz_host.cpp make_score_table); both ratios of token_set_ratio are lookups.
 // The table is indexed [lane][row] with an odd stride: lanes hit distinct banks for any row.
+// base + byte K of a wave-uniform word in ONE vector instruction (SDWA byte select on the scalar
+// operand).  The record's symbol bytes would otherwise each cost a scalar s_bfe before the v_add, and
+// the scalar unit is the busiest one in this kernel (profiles/r01_d_*: 0.78 SALU per CU-cycle).
+template <int K>
+__device__ __forceinline__ uint32_t fz_add_byte(uint32_t word, uint32_t base)
+{
+    uint32_t r;
+    if constexpr (K == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "s"(word), "v"(base));
+    if constexpr (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "s"(word), "v"(base));
+    if constexpr (K == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "s"(word), "v"(base));
+    if constexpr (K == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "s"(word), "v"(base));
+    return r;
+}
+
+// LDS byte address of a pointer into LDS, and a dword load from such an address.  With the address as
+// a plain integer the SDWA add above IS the address computation (no generic-pointer arithmetic left
+// for the compiler to redo).  The sanitizer build swaps the bodies for host ones (tests/emul).
+__device__ __forceinline__ uint32_t fz_lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;   // EMUL: return (uint32_t)((const unsigned char *)p - emul::g_lds);
+}
+__device__ __forceinline__ uint32_t fz_lds_load(uint32_t addr)
+{
+    return *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)addr;     // EMUL: return *(const uint32_t *)(emul::g_lds + addr);
+}
+
 template <int W, int STRIDE>
 __device__ __forceinline__ void fz_stream_step(uint32_t (&V)[W], const uint32_t (&row)[W], const uint32_t (&Mk)[W])
 {
@@ -481,7 +507,7 @@ __device__ __forceinline__ void fz_stream_step(uint32_t (&V)[W], const uint32_t 
 template <int W, int MODE, int STRIDE, int NT>
 __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const FzRec *__restrict__ recs,
                                                   uint8_t *__restrict__ scores, const uint8_t *s_tab,
-                                                  const uint8_t *col, const uint32_t (&cid)[FZ_STREAM_MAX_TOK],
+                                                  uint32_t col_off, const uint32_t (&cid)[FZ_STREAM_MAX_TOK],
                                                   const uint32_t (&Rm)[FZ_STREAM_MAX_TOK][W],
                                                   const uint32_t (&psep)[W], uint32_t clen, uint32_t out_off,
                                                   uint32_t qgroup)
@@ -526,12 +552,15 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
             const uint32_t id = cur.x, meta = cur.y, s03 = cur.z, s47 = cur.w;
             const uint32_t nsym = meta & 0xFFu;
             uint32_t row[8][W];
+            {
+                // LDS addresses of the eight rows in this lane's column: column address + symbol byte
+                const uint32_t o[8] = {fz_add_byte<0>(s03, col_off), fz_add_byte<1>(s03, col_off), fz_add_byte<2>(s03, col_off), fz_add_byte<3>(s03, col_off),
+                                       fz_add_byte<0>(s47, col_off), fz_add_byte<1>(s47, col_off), fz_add_byte<2>(s47, col_off), fz_add_byte<3>(s47, col_off)};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t b = ((k < 4 ? s03 : s47) >> (8 * (k & 3))) & 0xFFu;
+                for (int k = 0; k < 8; ++k)
 #pragma unroll
-                for (int w = 0; w < W; ++w)
-                    row[k][w] = *reinterpret_cast<const uint32_t *>(col + (uint32_t)w * PLANE + b);
+                    for (int w = 0; w < W; ++w)
+                        row[k][w] = fz_lds_load(o[k] + (uint32_t)w * PLANE);
             }
             if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x200u)) {
                 bool skip = false;
@@ -615,6 +644,7 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
     // draws `chunk` positions at a time from its home queue and moves on to the next queue when that
     // one is empty.  Exit: counters only grow, and a wave leaves when a scan finds every queue drained.
     uint8_t *col = s_peq + wave * ((uint32_t)W * PLANE) + lane * ((uint32_t)STRIDE * 4u);   // this lane's column
+    const uint32_t col_off = fz_lds_addr(col);
     uint32_t queue = (blockIdx.x + wave) % FZ_STREAM_QUEUES;
     uint32_t pos = 0u, pos_end = 0u;                     // positions [pos, pos_end) of `queue` are this wave's
     for (;;) {
@@ -702,12 +732,12 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
 
         // ---- the queries of this group: a stream of wave-uniform records (scalar loads) ------------
         const uint32_t out_off = tile * 64u + lane;
-        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
-        else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK>(p, recs, scores, s_tab, col, cid, Rm, psep, clen, out_off, qgroup);
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
     }
 }
 
