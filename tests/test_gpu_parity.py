@@ -201,3 +201,61 @@ def test_packed_corpus_file_roundtrip(oracle, tmp_path):
         f.truncate(100_000)
     with pytest.raises(_lib.FuzzyHipError):
         Corpus.load(path)
+
+
+def test_workspace_chunking_and_caller_stream(oracle):
+    """A tiny workspace limit forces many query chunks; a caller-provided stream carries the work:
+    results must not change."""
+    import torch
+    cps, offs = synth.make_corpus(20_000, max_chars=64, seed=101)
+    queries = synth.make_queries(cps, offs, 37, seed=102)
+    with Corpus(cps, offs) as c:
+        ref = c.topk(queries, 35, 10)
+        ref_all = c.score_all(queries[:5])
+        c.set_workspace_limit(3 * 20_032)          # three score rows at a time
+        got = c.topk(queries, 35, 10)
+        for a, b in zip(got, ref):
+            assert (a == b).all()
+        assert (c.score_all(queries[:5]) == ref_all).all()
+        st = torch.cuda.Stream()
+        c.set_stream(st.cuda_stream)
+        got = c.topk(queries, 35, 10)
+        for a, b in zip(got, ref):
+            assert (a == b).all()
+        c.set_stream(None)
+        c.set_workspace_limit(4 << 30)
+        got = c.topk(queries, 35, 10, _lib.PARTIAL)
+        cand = synth.to_strings(cps, offs)
+        buf, o = oracle.pack(cand)
+        e = oracle.topk(oracle.PARTIAL, queries[0], buf, o, 35, 10)
+        assert [(int(got[0][0, j]), int(got[1][0, j])) for j in range(int(got[2][0]))] == e
+
+
+def test_concurrent_callers_one_handle(oracle):
+    """The agent object is shared by every Streamlit session thread (reference
+    utils/helper_components.py:59-64): concurrent find_best_matches on one FuzzySearch."""
+    import threading
+    cps, offs = synth.make_corpus(30_000, max_chars=48, seed=111, vocab_size=300)
+    items = synth.to_strings(cps, offs)
+    queries = synth.make_queries(cps, offs, 24, seed=112, max_chars=48)
+    fs = FuzzySearch(items, items[:100], threshold=0.35)
+    expected = [fs.find_best_matches(q, "product") for q in queries]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(3):
+                for qi in range(tid, len(queries), 4):
+                    if fs.find_best_matches(queries[qi], "product") != expected[qi]:
+                        errors.append((tid, qi))
+        except Exception as exc:      # noqa: BLE001
+            errors.append((tid, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    fs.close()
+    assert not errors, errors[:3]
+    assert expected[0] == oracle.c_find_best_matches(items, queries[0], 0.35, 5)

@@ -22,6 +22,7 @@ GPU."""
 from __future__ import annotations
 
 import re
+import threading
 from collections import OrderedDict
 from difflib import SequenceMatcher
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -166,6 +167,7 @@ class AdvancedFuzzyMatcher:
 
     _indexes: "OrderedDict[int, Tuple[Sequence[str], CandidateIndex]]" = OrderedDict()
     _max_indexes = 8
+    _lock = threading.Lock()
     device = 0
 
     normalize_text = staticmethod(normalize_text)
@@ -178,24 +180,26 @@ class AdvancedFuzzyMatcher:
     @classmethod
     def index_for(cls, candidates: Sequence[str]) -> CandidateIndex:
         key = id(candidates)
-        ent = cls._indexes.get(key)
-        if ent is not None and ent[0] is candidates and ent[1].n == len(candidates):
-            cls._indexes.move_to_end(key)
-            return ent[1]
-        if ent is not None:
-            ent[1].close()
-        idx = CandidateIndex(candidates, device=cls.device)
-        cls._indexes[key] = (candidates, idx)
-        while len(cls._indexes) > cls._max_indexes:
-            _, (_, old) = cls._indexes.popitem(last=False)
-            old.close()
-        return idx
+        with cls._lock:
+            ent = cls._indexes.get(key)
+            if ent is not None and ent[0] is candidates and ent[1].n == len(candidates):
+                cls._indexes.move_to_end(key)
+                return ent[1]
+            if ent is not None:
+                ent[1].close()
+            idx = CandidateIndex(candidates, device=cls.device)
+            cls._indexes[key] = (candidates, idx)
+            while len(cls._indexes) > cls._max_indexes:
+                _, (_, old) = cls._indexes.popitem(last=False)
+                old.close()
+            return idx
 
     @classmethod
     def clear_cache(cls) -> None:
-        for _, idx in cls._indexes.values():
-            idx.close()
-        cls._indexes.clear()
+        with cls._lock:
+            for _, idx in cls._indexes.values():
+                idx.close()
+            cls._indexes.clear()
 
     # -- unit conversion shortcut (app.py:348-376), vectorised over the candidates ------------------
     @staticmethod
