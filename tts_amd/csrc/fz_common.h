@@ -83,7 +83,8 @@ struct FzScoreParams {
 #define FZ_STREAM_MAX_ROWS 63u    // Peq rows (distinct text symbols of one launch), row byte = 4*row < 256
 #define FZ_STREAM_QUEUES 32u      // work queues of one launch (each a contiguous range of items)
 #define FZ_STREAM_QPAD 64u        // u32 words between two queue counters (256 B: one counter per cache line)
-#define FZ_STREAM_TAB 128u        // score table is [FZ_STREAM_TAB][FZ_STREAM_TAB]: T[L][d], L, d < 128
+#define FZ_STREAM_TAB 128u        // score table covers length sums L < 128 ...
+#define FZ_STREAM_TAB_BYTES (FZ_STREAM_TAB * FZ_STREAM_TAB / 2u)   // ... as T[L][d >> 1]: d and L have the same parity
 #define FZ_QTOK_UNKNOWN 0xFFFFFFFEu   // token that is not in the corpus vocabulary
 #define FZ_QTOK_CONT 0xFFFFFFFDu      // continuation record of the previous token
 #define FZ_QTOK_PAD 0xFFFFFFFCu       // padding of an id record
@@ -108,7 +109,7 @@ struct FzStreamParams {
     const uint8_t *row_of_sym; // [256] corpus symbol -> 4 * row, 0xFF = no query of this launch uses it
     const FzRec *recs;         // record stream
     const uint32_t *qrec;      // [nq] index of each query's header record
-    const uint8_t *score_tab;  // [128*128] rounded ratio T[L*128 + d]
+    const uint8_t *score_tab;  // [128*64] rounded ratio T[L*64 + (d >> 1)], d of L's parity
     uint8_t *scores;
     uint32_t row_stride;       // bytes per score row (< 2^32)
 };

@@ -195,14 +195,15 @@ static uint32_t round_ratio_host(uint32_t d, uint32_t L, const FzTies &t)
     return q;
 }
 
-// stream kernel score table: T[L * 128 + d] = rounded ratio of distance d at length sum L
-// (d <= L < 128); T[0][0] = 100 is thefuzz's score of two empty strings under ratio().
+// stream kernel score table: T[L * 64 + (d >> 1)] = rounded ratio of distance d at length sum L
+// (d <= L < 128, d of L's parity); T[0][0] = 100 is thefuzz's score of two empty strings under ratio().
 static std::vector<uint8_t> make_score_table(const FzTies &t)
 {
-    std::vector<uint8_t> tab((size_t)FZ_STREAM_TAB * FZ_STREAM_TAB, 0);
+    std::vector<uint8_t> tab((size_t)FZ_STREAM_TAB_BYTES, 0);
     tab[0] = 100;
     for (uint32_t L = 1; L < FZ_STREAM_TAB; ++L)
-        for (uint32_t d = 0; d <= L; ++d) tab[(size_t)L * FZ_STREAM_TAB + d] = (uint8_t)round_ratio_host(d, L, t);
+        for (uint32_t d = L & 1u; d <= L; d += 2u)          // an InDel distance has the parity of the length sum
+            tab[(size_t)L * (FZ_STREAM_TAB / 2u) + (d >> 1)] = (uint8_t)round_ratio_host(d, L, t);
     return tab;
 }
 

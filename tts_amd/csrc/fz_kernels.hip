@@ -456,8 +456,9 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
 //     token that the candidate also has is scanned with an all-zero mask (it can match nothing).
 //   separator: every token of either side is followed by one separator; its
 //     match mask lives in a register, so the step after a token needs no lookup.
-//   score: T[L][d] = the rounded ratio, a 16 KiB table the host fills with the scorer's own
-//     rounding (fz_host.cpp make_score_table); both ratios of token_set_ratio are lookups.
+//   score: T[L][d >> 1] = the rounded ratio (a distance has the parity of its length sum, so half
+//     the columns suffice), an 8 KiB table the host fills with the scorer's own rounding
+//     (fz_host.cpp make_score_table); both ratios of token_set_ratio are lookups.
 // The table is indexed [lane][row] with an odd stride: lanes hit distinct banks for any row.
 // base + byte K of a wave-uniform word in ONE vector instruction (SDWA byte select on the scalar
 // operand).  The record's symbol bytes would otherwise each cost a scalar s_bfe before the v_add, and
@@ -604,14 +605,14 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
             for (int w = 0; w < W; ++w) sect1 += (uint32_t)__builtin_popcount(~M[w]);
             const uint32_t mc = m + clen;
             const uint32_t d0 = mc - 2u * (sect1 + lcs);
-            const uint32_t r0 = s_tab[(((mc - 2u) << 7) + d0) & 0x3FFFu];
+            const uint32_t r0 = s_tab[(((mc - 2u) << 6) + (d0 >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
             const uint32_t d1 = (m < clen ? m : clen) - sect1;
-            const uint32_t r1 = s_tab[(((2u * sect1 - 2u + d1) << 7) + d1) & 0x3FFFu];
+            const uint32_t r1 = s_tab[(((2u * sect1 - 2u + d1) << 6) + (d1 >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
             sc = (sect1 != 0u && r1 > r0) ? r1 : r0;
             if (clen == 0u) sc = 0u;                                  // a candidate without tokens scores 0
         } else {
             const uint32_t L = m + clen;
-            sc = s_tab[((L << 7) + (L - 2u * lcs)) & 0x3FFFu];        // T[0][0] = 100: two empty strings
+            sc = s_tab[((L << 6) + ((L - 2u * lcs) >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];   // T[0][0] = 100: two empty strings
         }
         uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
         rowp[out_off] = (uint8_t)sc;
@@ -624,14 +625,14 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
                                                         uint8_t *__restrict__ scores)
 {
     extern __shared__ __align__(16) uint32_t lds[];
-    uint8_t *s_tab = reinterpret_cast<uint8_t *>(lds);                   // [128][128] rounded ratios
-    uint8_t *s_row = s_tab + FZ_STREAM_TAB * FZ_STREAM_TAB;              // [256] symbol -> 4 * row
+    uint8_t *s_tab = reinterpret_cast<uint8_t *>(lds);                   // [128][64] rounded ratios T[L][d >> 1]
+    uint8_t *s_row = s_tab + FZ_STREAM_TAB_BYTES;                        // [256] symbol -> 4 * row
     uint8_t *s_peq = s_row + 256u;                                       // [nwaves][W][64][STRIDE] u32
     constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;              // bytes of one word plane
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    for (uint32_t i = tid; i < FZ_STREAM_TAB * FZ_STREAM_TAB / 16u; i += blockDim.x)
+    for (uint32_t i = tid; i < FZ_STREAM_TAB_BYTES / 16u; i += blockDim.x)
         reinterpret_cast<uint4 *>(s_tab)[i] = reinterpret_cast<const uint4 *>(p.score_tab)[i];
     if (tid < 64u) reinterpret_cast<uint32_t *>(s_row)[tid] = reinterpret_cast<const uint32_t *>(p.row_of_sym)[tid];
     __syncthreads();                                                     // the only block-wide barrier
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
 
 size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves)
 {
-    return (size_t)FZ_STREAM_TAB * FZ_STREAM_TAB + 256u + (size_t)nwaves * W * 64u * stride * 4u;
+    return (size_t)FZ_STREAM_TAB_BYTES + 256u + (size_t)nwaves * W * 64u * stride * 4u;
 }
 
 template <int W, int MODE, int STRIDE>
