@@ -8,7 +8,7 @@ thresholded, top-k selected; for N > 1 the per-GPU top-k keys are all-gathered (
 Workload at N=1 = BASELINE.json configs[1] (C2: 1k queries x 1M candidates <= 64 chars, k=10).
 Weak scaling: every rank holds its own `--candidates`-sized shard (contiguous global index range).
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 Prints ONE JSON line on rank 0.
@@ -68,8 +68,8 @@ def cpu_baseline(cps, offs, queries, min_score, k, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["C2", "C4"], default="C2",
                     help="C2 (default, the metric's configuration): names <= 64 chars; C4: long strings "
                          "64-512 chars (multi-word carry chain), an extra measurement, not the bench line")

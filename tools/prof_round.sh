@@ -3,7 +3,7 @@ TAG=${1:-r01x}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
 timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $O/${TAG}_tests.log 2>&1
-timeout -k 10 300 python bench.py --steps 5 --warmup 1 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+timeout -k 10 300 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-reps 0"
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -o ${TAG} -- $B > $O/${TAG}_trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o p -- $B > $O/${TAG}_pmc_fetch.log 2>&1
