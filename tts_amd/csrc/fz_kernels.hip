@@ -787,7 +787,7 @@ hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_
 // ---------------------------------------------------------------------------------------------
 // top-k selection
 // ---------------------------------------------------------------------------------------------
-#define SEL_THREADS 512u       // fz_select_topk: 8 waves per row (4 rows per CU resident: 1000 rows in one round)
+#define SEL_THREADS 1024u      // fz_select_topk: 16 waves per row
 #define SEL_WAVES (SEL_THREADS / 64u)
 #define SEL16_THREADS 256u     // fz_select16_topk: one thread per histogram bin
 #define SEL_TIECAP 2048u
