@@ -59,10 +59,21 @@ def cpu_baseline(cps, offs, queries, min_score, k, budget_s=12.0):
     for q in queries[:nqs]:
         O.topk(O.TOKEN_SET, q, cps, sub_offs, min_score, k)
     dt = time.perf_counter() - t0
+    out = {"value": nqs * ncand / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+           "sample": f"{nqs} queries x first {ncand} candidates of the same corpus, "
+                     f"oracle/fuzz_oracle.c token_set_ratio + top-{k} loop, {dt:.1f} s"}
+    # the same loop on the host cores this job may use (ctypes releases the GIL): SURVEY.md 8d, B2
+    from concurrent.futures import ThreadPoolExecutor
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    qs = (queries * ((nqs * threads) // max(len(queries), 1) + 1))[:nqs * threads]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda q: O.topk(O.TOKEN_SET, q, cps, sub_offs, min_score, k), qs))
+    dt = time.perf_counter() - t0
+    out["all_cores"] = {"value": len(qs) * ncand / dt, "unit": "pairs/s", "cores": threads,
+                        "sample": f"{len(qs)} queries x {ncand} candidates over {threads} threads, {dt:.1f} s"}
     O.lib().orc_set_bitpar(0)
-    return {"value": nqs * ncand / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{nqs} queries x first {ncand} candidates of the same corpus, "
-                      f"oracle/fuzz_oracle.c token_set_ratio + top-{k} loop, {dt:.1f} s"}
+    return out
 
 
 def main():
