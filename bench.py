@@ -112,10 +112,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # FUZZYHIP_BENCH_REHEARSAL=1: several ranks share the visible GPUs and exchange over gloo -- a way
+    # to run the N > 1 code path on a one-GPU box; never the measured configuration
+    rehearsal = os.environ.get("FUZZYHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # this rank's shard: its own seeded corpus, global indices [rank*n, (rank+1)*n)
     n = args.candidates
@@ -140,13 +148,13 @@ def main():
     keys_dev = gathered = None
     if world > 1:
         keys_dev = torch.zeros(nq * k, dtype=torch.int64, device="cuda")
-        gathered = torch.zeros(world * nq * k, dtype=torch.int64, device="cuda")
+        gathered = torch.zeros(world * nq * k, dtype=torch.int64, device="cpu" if rehearsal else "cuda")
 
     def step():
         if world == 1:
             return corpus.topk(q_packed, min_score, k)
         corpus.topk_keys_device(q_packed, min_score, k, keys_dev.data_ptr(), 0, sync=True)
-        dist.all_gather_into_tensor(gathered, keys_dev)
+        dist.all_gather_into_tensor(gathered, keys_dev.cpu() if rehearsal else keys_dev)
         host = gathered.cpu().numpy().view(np.uint64)
         return merge_topk(host, world, nq, k)
 
@@ -170,7 +178,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -196,7 +204,7 @@ def main():
                                    (f"C2: {nq} queries x {n} candidates/GPU (<= {args.max_chars} chars, "
                                     f"Zipf(1.2) tokens over 50k vocabulary), top-{k}, threshold {args.threshold}"),
                        "queries": nq, "candidates_per_gpu": n, "k": k, "min_score": min_score,
-                       "parallelism": f"shard{world}" if world > 1 else "single"},
+                       "parallelism": (f"shard{world}" if world > 1 else "single") + ("-rehearsal-gloo" if rehearsal else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per step)" if traffic else None,
