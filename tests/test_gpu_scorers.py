@@ -63,9 +63,10 @@ def test_config5_unicode_all_scorers(oracle):
             bad = np.argwhere(got != exp)
             assert bad.size == 0, (sc, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])
     with Corpus.from_prepared(cand) as c:
-        got = c.score_all(queries, _lib.RATIO)
-        exp = np.stack([oracle.score_all(oracle.RATIO, q, buf, o) for q in queries]).astype(np.uint8)
-        assert (got == exp).all()
+        for sc, orc in ((_lib.RATIO, oracle.RATIO), (_lib.PARTIAL, oracle.PARTIAL)):
+            got = c.score_all(queries, sc)
+            exp = np.stack([oracle.score_all(orc, q, buf, o) for q in queries]).astype(np.uint8)
+            assert (got == exp).all(), sc
 
 
 def test_distances_all_lengths(oracle):
