@@ -272,3 +272,22 @@ def test_common_tokens_and_substring(oracle, runner, tmp_path):
     for qi, q in enumerate(pats):
         for i, s in enumerate(text):
             assert int(got[qi, i]) == (1 if q in s else 0), (q, s)
+
+
+def test_limits_long_strings(oracle, runner, tmp_path):
+    """the longest supported shapes: 32-word patterns, candidates of thousands of symbols"""
+    import random
+    rnd = random.Random(71)
+    words = ["".join(rnd.choice("abcdefgh") for _ in range(rnd.randint(2, 7))) for _ in range(400)]
+    long_c = " ".join(rnd.choice(words) for _ in range(700))            # ~3500 chars
+    long_q = " ".join(rnd.choice(words) for _ in range(170))[:1000].strip()
+    cand = [long_c, long_q, "ab cd", "", " ".join(words[:150])] + [" ".join(rnd.choice(words) for _ in range(rnd.randint(1, 60))) for _ in range(70)]
+    queries = [long_q, "ab cd", " ".join(words[:150])]
+    got = _run(runner, tmp_path, 0, 0, cand, queries)
+    assert (got == _oracle_scores(oracle, oracle.TOKEN_SET, queries, cand)).all()
+    raw_q = long_q.replace(" ", "")[:1000]
+    for kind, fn in ((0, oracle.indel), (1, oracle.levenshtein)):
+        got = _run(runner, tmp_path, 1, kind, cand[:12], [raw_q, "abc"])
+        for qi, q in enumerate([raw_q, "abc"]):
+            for i, s in enumerate(cand[:12]):
+                assert int(got[qi, i]) == fn(q, s), (kind, len(q), len(s))
