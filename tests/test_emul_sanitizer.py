@@ -45,6 +45,7 @@ def _run(runner, tmp_path, op, sk, cand, queries, min_score=0, k=0, env=None):
     e.update(env or {})
     r = subprocess.run([runner, case, out], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
+    _run.last_stderr = r.stderr
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
     raw = np.fromfile(out, dtype=np.uint8)
     if op in (0, 4):
@@ -71,6 +72,21 @@ def test_token_set_scores_short(oracle, runner, tmp_path, no_stream):
     exp = _oracle_scores(oracle, oracle.TOKEN_SET, queries, cand)
     bad = np.argwhere(got != exp)
     assert bad.size == 0, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]]
+
+
+def test_packed_short_tiles(oracle, runner, tmp_path):
+    """candidates of at most 15 symbols go to the packed stream kernel, two tiles per wave (7 tiles:
+    the odd last one is scored alone); every streamed scorer against the oracle"""
+    cps, offs = synth.make_corpus(420, max_chars=14, seed=21, vocab_size=60, max_tokens=4)
+    cand = synth.to_strings(cps, offs) + ["", "a", "abcdefghijklmn", "ab cd ef gh", "a b c d"]
+    queries = synth.make_queries(cps, offs, 9, seed=22) + ["", cand[5], "zz top", "y" * 70, "a b c d e f",
+                                                            cand[17] + " " + cand[40]]
+    for sk, orc in ((0, oracle.TOKEN_SET), (1, oracle.RATIO), (2, oracle.TOKEN_SORT)):
+        got = _run(runner, tmp_path, 0, sk, cand, queries, env={"FUZZYHIP_TRACE": "1"})
+        assert "7 tiles -> packed 7," in _run.last_stderr, _run.last_stderr[-500:]
+        exp = _oracle_scores(oracle, orc, queries, cand)
+        bad = np.argwhere(got != exp)
+        assert bad.size == 0, (sk, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])
 
 
 def test_token_set_multiword(oracle, runner, tmp_path):

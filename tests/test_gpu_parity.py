@@ -35,6 +35,26 @@ def test_score_matrix_synthetic_short(oracle):
     assert bad.size == 0, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]]
 
 
+def test_packed_short_candidates(oracle):
+    """candidates of at most 15 symbols: the packed stream kernel (two tiles per wave), mixed with
+    longer ones that stay in the plain stream kernel; token_set, ratio and token_sort"""
+    cps_a, offs_a = synth.make_corpus(2500, max_chars=14, seed=31, vocab_size=200, max_tokens=4)
+    cps_b, offs_b = synth.make_corpus(900, max_chars=64, seed=32, vocab_size=200)
+    cand = synth.to_strings(cps_a, offs_a) + synth.to_strings(cps_b, offs_b) + ["", "a", "abcdefghijklmn", "a b c d"]
+    rng = np.random.default_rng(33)
+    cand = [cand[int(i)] for i in rng.permutation(len(cand))]
+    queries = synth.make_queries(cps_a, offs_a, 30, seed=34) + synth.make_queries(cps_b, offs_b, 20, seed=35)
+    queries += ["", "zz", cand[5], cand[7] + " extra tok", "a b c d e f g h i"]
+    buf, offs = oracle.pack(cand)
+    with Corpus.from_prepared(cand) as c:
+        for sk, orc in ((_lib.TOKEN_SET, oracle.TOKEN_SET), (_lib.RATIO, oracle.RATIO), (_lib.TOKEN_SORT, oracle.TOKEN_SORT)):
+            got = c.score_all(queries, sk)
+            exp = np.stack([oracle.score_all(orc, q, buf, offs) for q in queries]).astype(np.uint8)
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (sk, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])
+        _check_topk(oracle, c, queries, cand, 35, 10)
+
+
 def test_topk_order_under_ties(oracle):
     # tiny vocabulary => massive score ties; order must be (score desc, original index asc)
     cps, offs = synth.make_corpus(5000, max_chars=32, seed=3, vocab_size=12)

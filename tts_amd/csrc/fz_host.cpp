@@ -29,6 +29,7 @@ hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq,
 hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st);
 size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves);
 hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_t st);
+hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st);
 hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_t st);
 hipError_t fz_launch_select16(const FzSelect16Params &p, uint32_t rows, hipStream_t st);
 
@@ -119,8 +120,9 @@ struct View {
     uint16_t *d_tokend = nullptr;
     FzTile *d_tiles = nullptr;
     // tile indices by kernel: stream kernel with 1 / 2 pattern words, general kernel for the rest
-    uint32_t *d_tiles_s1 = nullptr, *d_tiles_s2 = nullptr, *d_tiles_slow = nullptr;
-    uint32_t n_s1 = 0, n_s2 = 0, n_slow = 0;
+    // (s0: candidates of at most 15 symbols, taken two tiles at a time by the packed stream kernel)
+    uint32_t *d_tiles_s0 = nullptr, *d_tiles_s1 = nullptr, *d_tiles_s2 = nullptr, *d_tiles_slow = nullptr;
+    uint32_t n_s0 = 0, n_s1 = 0, n_s2 = 0, n_slow = 0;
     std::vector<uint32_t> h_orig_of_phys;
 };
 
@@ -233,7 +235,7 @@ extern "C" int fz_device_count(int *out_n)
 static void free_view(View &v)
 {
     for (void *p : {(void *)v.d_sym, (void *)v.d_tokid, (void *)v.d_tokend, (void *)v.d_tiles,
-                    (void *)v.d_orig_of_phys, (void *)v.d_phys_of_orig, (void *)v.d_tiles_s1,
+                    (void *)v.d_orig_of_phys, (void *)v.d_phys_of_orig, (void *)v.d_tiles_s0, (void *)v.d_tiles_s1,
                     (void *)v.d_tiles_s2, (void *)v.d_tiles_slow})
         if (p) (void)hipFree(p);
     v = View();
@@ -254,17 +256,24 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
 }
 
 // tile indices by kernel: stream kernel with one / two pattern words, general kernel for the rest
-static int upload_tile_lists(View &v, const std::vector<FzTile> &tiles)
+static int upload_tile_lists(View &v, const std::vector<FzTile> &tiles, const std::vector<uint32_t> &tile_maxlen)
 {
-    std::vector<uint32_t> ts1, ts2, tslow;
+    std::vector<uint32_t> ts0, ts1, ts2, tslow;
+    const bool pack = getenv("FUZZYHIP_NO_PACK") == nullptr;      // experiments: keep short tiles in the plain kernel
     for (uint32_t t = 0; t < v.ntiles; ++t) {
         // the stream kernel keeps one Peq row per symbol byte: 8-bit symbols only
-        if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
+        if (pack && !v.wide && tiles[t].ntok <= FZ_PK_MAX_TOK && tile_maxlen[t] <= 15u) ts0.push_back(t);
+        else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
         else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
         else tslow.push_back(t);
     }
+    v.n_s0 = (uint32_t)ts0.size();
     v.n_s1 = (uint32_t)ts1.size(); v.n_s2 = (uint32_t)ts2.size(); v.n_slow = (uint32_t)tslow.size();
+    if (getenv("FUZZYHIP_TRACE"))
+        fprintf(stderr, "fuzzyhip: %u tiles -> packed %u, stream1 %u, stream2 %u, general %u\n",
+                v.ntiles, v.n_s0, v.n_s1, v.n_s2, v.n_slow);
     int rc;
+    if ((rc = upload(&v.d_tiles_s0, ts0, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_tiles_s1, ts1, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_tiles_s2, ts2, &v.device_bytes)) != FZ_OK) return rc;
     return upload(&v.d_tiles_slow, tslow, &v.device_bytes);
@@ -369,6 +378,7 @@ static int build_view(fz_corpus *c, int kind)
         phys_of_orig[o] = (uint32_t)ph;
     }
     std::vector<FzTile> tiles(v.ntiles);
+    std::vector<uint32_t> tile_maxlen(v.ntiles, 0u);
     uint64_t sym_words = 0, tok_slots = 0;
     for (uint32_t t = 0; t < v.ntiles; ++t) {
         uint32_t ndw = 0, ntok = 0;
@@ -376,6 +386,7 @@ static int build_view(fz_corpus *c, int kind)
             uint64_t ph = (uint64_t)t * FZ_TILE + l;
             if (ph >= n) break;
             uint32_t o = v.h_orig_of_phys[ph];
+            tile_maxlen[t] = std::max<uint32_t>(tile_maxlen[t], (uint32_t)(canon_off[o + 1] - canon_off[o]));
             ndw = std::max<uint32_t>(ndw, (uint32_t)((canon_off[o + 1] - canon_off[o] + spd - 1) / spd));
             ntok = std::max<uint32_t>(ntok, (uint32_t)(tok_off[o + 1] - tok_off[o]));
         }
@@ -419,7 +430,7 @@ static int build_view(fz_corpus *c, int kind)
     if ((rc = upload(&v.d_tiles, tiles, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_orig_of_phys, v.h_orig_of_phys, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_phys_of_orig, phys_of_orig, &v.device_bytes)) != FZ_OK) return rc;
-    if ((rc = upload_tile_lists(v, tiles)) != FZ_OK) return rc;
+    if ((rc = upload_tile_lists(v, tiles, tile_maxlen)) != FZ_OK) return rc;
     v.built = true;
     return FZ_OK;
 }
@@ -625,6 +636,7 @@ extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index,
             v.sym_of_cp[alpha[i]] = (uint16_t)alpha[i + 1];
         }
         std::vector<FzTile> tiles(v.ntiles);
+        std::vector<uint32_t> tile_maxlen(v.ntiles, 0u);
         {
             std::vector<uint32_t> h_sym(v.n_sym_words), h_tokid(v.n_tok_slots);
             std::vector<uint16_t> h_tokend(v.n_tok_slots);
@@ -648,6 +660,8 @@ extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index,
                         if (e < prev || e > (uint32_t)t.ndw * spd) return bad("token end outside its candidate");
                         prev = e;
                     }
+                    uint32_t &ml = tile_maxlen[&t - tiles.data()];     // the last slot's end is the length
+                    ml = std::max(ml, prev);
                 }
             }
             if ((rc = upload(&v.d_sym, h_sym, &v.device_bytes)) != FZ_OK) break;
@@ -667,7 +681,7 @@ extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index,
                 if (pofo[o] >= c->n || v.h_orig_of_phys[pofo[o]] != o) return bad("permutations do not invert each other");
             if ((rc = upload(&v.d_phys_of_orig, pofo, &v.device_bytes)) != FZ_OK) break;
         }
-        rc = upload_tile_lists(v, tiles);
+        rc = upload_tile_lists(v, tiles, tile_maxlen);
         if (rc != FZ_OK) break;
         v.built = true;
     }
@@ -980,7 +994,7 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
     auto t0 = std::chrono::steady_clock::now();
     QueryBatch b;
     const bool stream_mode = kmode == FZ_MODE_TOKEN_SET || kmode == FZ_MODE_RATIO;
-    b.allow_stream = c->use_stream && stream_mode && (v.n_s1 + v.n_s2) > 0 && row_stride <= 0xFFFFFFFFull;
+    b.allow_stream = c->use_stream && stream_mode && (v.n_s0 + v.n_s1 + v.n_s2) > 0 && row_stride <= 0xFFFFFFFFull;
     // the score table covers L < 128; a stream tile holds at most 64 symbols.  token_set looks up
     // L = m + clen - 2, ratio L = m + clen.
     b.stream_max_m = kmode == FZ_MODE_TOKEN_SET ? (FZ_STREAM_TAB + 1u - 64u) : (FZ_STREAM_TAB - 1u - 64u);
@@ -1075,24 +1089,26 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
         // odd strides keep the 64 lane columns on distinct banks; the smallest one that holds the rows of
         // this launch leaves room for the most waves (37: a-z, 0-9 and one spare)
         const uint32_t stride = b.nrows <= 37u ? 37u : (b.nrows <= 41u ? 41u : 65u);
-        for (int W = 1; W <= 2; ++W) {
-            const uint32_t nt = W == 1 ? v.n_s1 : v.n_s2;
+        for (int cls = 0; cls <= 2; ++cls) {           // 0: packed pairs of short tiles, 1 / 2: pattern words
+            const int W = cls == 2 ? 2 : 1;
+            const uint32_t nt = cls == 0 ? v.n_s0 : (cls == 1 ? v.n_s1 : v.n_s2);
             if (nt == 0) continue;
+            const uint32_t units = cls == 0 ? (nt + 1u) / 2u : nt;      // tiles (or tile pairs) to hand out
             FzStreamParams p{};
             p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
-            p.tile_list = W == 1 ? v.d_tiles_s1 : v.d_tiles_s2;
+            p.tile_list = cls == 0 ? v.d_tiles_s0 : (cls == 1 ? v.d_tiles_s1 : v.d_tiles_s2);
             p.ntiles = nt; p.stride = stride;
             p.nwaves = 16;
             while (p.nwaves > 1 && fz_stream_lds_bytes(W, (int)stride, p.nwaves) > 160 * 1024) --p.nwaves;
             p.nwaves = std::min<uint32_t>(p.nwaves, std::max<uint32_t>(1, c->stream_waves));
             p.nq = (uint32_t)b.qrec.size();
             // enough blocks to balance the chip, enough queries per block to amortise the tile set-up
-            const uint64_t bx = (nt + p.nwaves - 1) / p.nwaves;
+            const uint64_t bx = (units + p.nwaves - 1) / p.nwaves;
             uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (c->stream_blocks + bx - 1) / bx));
             p.q_per_block = (uint32_t)((p.nq + by - 1) / by);
             const uint64_t groups = (p.nq + p.q_per_block - 1) / p.q_per_block;
-            if ((uint64_t)nt * groups > 0xFFFFFF00ull) return fail(FZ_ERR_LIMIT, "too many work items in one launch");
-            p.nitems = (uint32_t)((uint64_t)nt * groups);
+            if ((uint64_t)units * groups > 0xFFFFFF00ull) return fail(FZ_ERR_LIMIT, "too many work items in one launch");
+            p.nitems = (uint32_t)((uint64_t)units * groups);
             // as many persistent blocks as fit the chip at this LDS size; each drains the work queue
             const size_t lds_b = fz_stream_lds_bytes(W, (int)stride, p.nwaves);
             p.grid_blocks = c->n_cus * (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_b) * c->stream_oversub;
@@ -1107,7 +1123,8 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
             p.qrec = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_qrec);
             p.score_tab = c->d_score_tab[kmode == FZ_MODE_TOKEN_SET ? 0 : 1];
             p.scores = c->d_scores; p.row_stride = (uint32_t)row_stride;
-            HIP_TRY(fz_launch_stream(W, kmode, p, st));
+            if (cls == 0) HIP_TRY(fz_launch_stream_pk(kmode, p, st));
+            else HIP_TRY(fz_launch_stream(W, kmode, p, st));
             c->timing.score_launches++;
         }
     }

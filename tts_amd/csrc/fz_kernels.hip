@@ -742,6 +742,219 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// packed stream kernel: TWO short candidates per lane in one 32-bit pattern word
+// ---------------------------------------------------------------------------------------------
+// Tiles whose candidates have at most 15 symbols are taken two at a time: tile A lives in bits 0..14
+// of every pattern word of the lane, tile B in bits 16..30.  One LDS row read and one Hyyro update
+// then serve two candidates.  Bit 15 is the carry stopper: it is 1 in V and 0 in every match mask, and
+// it is cleared in the addend, so the carry chain of A ends there (bit 15 of the sum is dropped by the
+// OR with V ^ u, whose bit 15 is always 1) and never reaches B; the carry out of bit 31 is discarded by
+// the 32-bit add.  Everything else is the stream kernel above, with the per-candidate pieces doubled.
+#define FZ_PK_FIELD 0x7FFFu
+
+template <int MODE, int STRIDE, int NT>
+__device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, const FzRec *__restrict__ recs,
+                                                     uint8_t *__restrict__ scores, const uint8_t *s_tab,
+                                                     uint32_t col_off, const uint32_t (&cid)[2][FZ_PK_MAX_TOK],
+                                                     const uint32_t (&Rm)[2][FZ_PK_MAX_TOK], uint32_t psep,
+                                                     const uint32_t (&clen)[2], const uint32_t (&out_off)[2],
+                                                     uint32_t qgroup)
+{
+    uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
+    if (q1 > p.nq) q1 = p.nq;
+    uint32_t ri = p.qrec[q0];
+    FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with two padding records
+#define FZ_ADVANCE() do { cur = nxt; nxt = recs[ri + 2u]; ++ri; } while (0)
+
+    for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t out_row = cur.x, m = cur.y;
+        const uint32_t n_ids = cur.z & 0xFFFFu, nrec = cur.z >> 16;
+        FZ_ADVANCE();
+
+        uint32_t M = 0xFFFFFFFFu;
+        if (MODE == FZ_MODE_TOKEN_SET) {
+            // a candidate token the query also has leaves the pattern: its range is cleared in M at once
+            // (no per-token lane masks to carry through the loop: sixteen of them would not fit the SGPRs)
+            for (uint32_t j = 0; j < n_ids; j += 4u) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const bool c = (cid[h][i] == cur.x) | (cid[h][i] == cur.y) | (cid[h][i] == cur.z) | (cid[h][i] == cur.w);
+                        M &= c ? ~Rm[h][i] : 0xFFFFFFFFu;
+                    }
+                FZ_ADVANCE();
+            }
+        }
+
+        uint32_t V = 0xFFFFFFFFu, Mk = M;
+        for (uint32_t r = 0; r < nrec; ++r) {
+            const uint32_t id = cur.x, meta = cur.y, s03 = cur.z, s47 = cur.w;
+            const uint32_t nsym = meta & 0xFFu;
+            uint32_t row[8];
+            {
+                const uint32_t o[8] = {fz_add_byte<0>(s03, col_off), fz_add_byte<1>(s03, col_off), fz_add_byte<2>(s03, col_off), fz_add_byte<3>(s03, col_off),
+                                       fz_add_byte<0>(s47, col_off), fz_add_byte<1>(s47, col_off), fz_add_byte<2>(s47, col_off), fz_add_byte<3>(s47, col_off)};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) row[k] = fz_lds_load(o[k]);
+            }
+            if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x200u)) {
+                // a token both sides have is scanned with a zero mask, per half
+                bool skip[2] = {false, false};
+                if (meta & 0x400u) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) skip[h] |= cid[h][i] == id;
+                }
+                Mk = M & (skip[0] ? 0xFFFF0000u : 0xFFFFFFFFu) & (skip[1] ? 0x0000FFFFu : 0xFFFFFFFFu);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(row[k]) : : "memory");
+            FZ_ADVANCE();
+#define FZ_PK_STEP(rw) do { const uint32_t v_ = V; const uint32_t u_ = __builtin_amdgcn_bitop3_b32(v_, (rw), Mk, 0x80); \
+                            V = __builtin_amdgcn_bitop3_b32((v_ & 0xFFFF7FFFu) + u_, v_, u_, 0xF6); } while (0)
+            if (nsym > 0u) { FZ_PK_STEP(row[0]);
+            if (nsym > 1u) { FZ_PK_STEP(row[1]);
+            if (nsym > 2u) { FZ_PK_STEP(row[2]);
+            if (nsym > 3u) { FZ_PK_STEP(row[3]);
+            if (nsym > 4u) { FZ_PK_STEP(row[4]);
+            if (nsym > 5u) { FZ_PK_STEP(row[5]);
+            if (nsym > 6u) { FZ_PK_STEP(row[6]);
+            if (nsym > 7u) { FZ_PK_STEP(row[7]); } } } } } } } }
+            if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x100u)) FZ_PK_STEP(psep);
+#undef FZ_PK_STEP
+        }
+
+        uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t lcs = (uint32_t)__builtin_popcount((~V >> (16 * h)) & FZ_PK_FIELD);
+            uint32_t sc;
+            if (MODE == FZ_MODE_TOKEN_SET) {
+                const uint32_t sect1 = (uint32_t)__builtin_popcount((~M >> (16 * h)) & FZ_PK_FIELD);
+                const uint32_t mc = m + clen[h];
+                const uint32_t d0 = mc - 2u * (sect1 + lcs);
+                const uint32_t r0 = s_tab[(((mc - 2u) << 6) + (d0 >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
+                const uint32_t d1 = (m < clen[h] ? m : clen[h]) - sect1;
+                const uint32_t r1 = s_tab[(((2u * sect1 - 2u + d1) << 6) + (d1 >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
+                sc = (sect1 != 0u && r1 > r0) ? r1 : r0;
+                if (clen[h] == 0u) sc = 0u;                           // a candidate without tokens scores 0
+            } else {
+                const uint32_t L = m + clen[h];
+                sc = s_tab[((L << 6) + ((L - 2u * lcs) >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
+            }
+            rowp[out_off[h]] = (uint8_t)sc;
+        }
+    }
+#undef FZ_ADVANCE
+}
+
+template <int MODE, int STRIDE>
+__global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, const FzRec *__restrict__ recs,
+                                                           uint8_t *__restrict__ scores)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint8_t *s_tab = reinterpret_cast<uint8_t *>(lds);                   // [128][64] rounded ratios T[L][d >> 1]
+    uint8_t *s_row = s_tab + FZ_STREAM_TAB_BYTES;                        // [256] symbol -> 4 * row
+    uint8_t *s_peq = s_row + 256u;                                       // [nwaves][64][STRIDE] u32
+    constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    for (uint32_t i = tid; i < FZ_STREAM_TAB_BYTES / 16u; i += blockDim.x)
+        reinterpret_cast<uint4 *>(s_tab)[i] = reinterpret_cast<const uint4 *>(p.score_tab)[i];
+    if (tid < 64u) reinterpret_cast<uint32_t *>(s_row)[tid] = reinterpret_cast<const uint32_t *>(p.row_of_sym)[tid];
+    __syncthreads();                                                     // the only block-wide barrier
+
+    uint8_t *col = s_peq + wave * PLANE + lane * ((uint32_t)STRIDE * 4u);   // this lane's column
+    const uint32_t col_off = fz_lds_addr(col);
+    const uint32_t npairs = (p.ntiles + 1u) / 2u;                        // an item = (query group, pair of tiles)
+    uint32_t queue = (blockIdx.x + wave) % FZ_STREAM_QUEUES;
+    uint32_t pos = 0u, pos_end = 0u;
+    for (;;) {
+        if (pos >= pos_end) {                                            // same queue protocol as fz_score_stream
+            const uint32_t q_len = queue < p.nitems ? (p.nitems - queue + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES : 0u;
+            uint32_t *cnt = p.work_counter + queue * FZ_STREAM_QPAD;
+            uint32_t got = 0xFFFFFFFFu;
+            if (lane == 0u && q_len != 0u && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_len)
+                got = atomicAdd(cnt, p.chunk);
+            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            if (got >= q_len) {
+                bool open = false;
+                if (lane < FZ_STREAM_QUEUES && lane < p.nitems) {
+                    const uint32_t len_l = (p.nitems - lane + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES;
+                    open = __hip_atomic_load(p.work_counter + lane * FZ_STREAM_QPAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len_l;
+                }
+                const uint64_t mask = __ballot(open);
+                if (mask == 0ull) break;
+                const uint64_t ahead = mask >> queue;
+                queue = ahead != 0ull ? queue + (uint32_t)__builtin_ctzll(ahead) : (uint32_t)__builtin_ctzll(mask);
+                continue;
+            }
+            pos = got;
+            pos_end = got + p.chunk < q_len ? got + p.chunk : q_len;
+        }
+        const uint32_t item = queue + pos * FZ_STREAM_QUEUES;
+        ++pos;
+        const uint32_t qgroup = item / npairs, pair = item - qgroup * npairs;
+
+        // ---- candidate side: two tiles, once per item --------------------------------------------
+        for (uint32_t r = 0; r < (uint32_t)STRIDE; ++r) *reinterpret_cast<uint32_t *>(col + r * 4u) = 0u;
+        uint32_t cid[2][FZ_PK_MAX_TOK], Rm[2][FZ_PK_MAX_TOK], clen[2], out_off[2], psep = 0u, ntok = 0u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // an odd tile count: the last item scores its one tile in both halves (same values, same addresses)
+            const uint32_t tix = 2u * pair + (uint32_t)h < p.ntiles ? 2u * pair + (uint32_t)h : 2u * pair;
+            const uint32_t tile = p.tile_list[tix];
+            const FzTile td = p.tiles[tile];
+            out_off[h] = tile * 64u + lane;
+            if (td.ntok > ntok) ntok = td.ntok;
+            uint32_t prev_end = 0u;
+#pragma unroll
+            for (int i = 0; i < (int)FZ_PK_MAX_TOK; ++i) {
+                uint32_t end = prev_end;
+                cid[h][i] = FZ_TOK_NONE;
+                if ((uint32_t)i < td.ntok) {
+                    if (MODE == FZ_MODE_TOKEN_SET) cid[h][i] = p.tokid[td.toff + (uint32_t)i * 64u + lane];
+                    end = p.tokend[td.toff + (uint32_t)i * 64u + lane];
+                }
+                if (end > 15u) end = 15u;                                // host guarantee; keeps the shifts defined
+                Rm[h][i] = (((1u << end) - 1u) & ~((1u << prev_end) - 1u)) << (16 * h);   // pattern positions of token i
+                prev_end = end;
+            }
+            clen[h] = prev_end;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if ((uint32_t)d < td.ndw) {
+                    const uint32_t cw = p.sym[td.coff + (uint32_t)d * 64u + lane];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t s = (cw >> (8 * k)) & 0xFFu;
+                        if (d * 4 + k < 15) {
+                            const uint32_t bit = 1u << (d * 4 + k + 16 * h);
+                            if (MODE == FZ_MODE_TOKEN_SET && s == FZ_SYM_SPACE) {
+                                psep |= bit;
+                            } else {
+                                const uint32_t r4 = s_row[s];            // 0xFF: no query uses this symbol
+                                if (r4 != 0xFFu)
+                                    __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(col + r4), bit,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        ntok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ntok);
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+    }
+}
+
 size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves)
 {
     return (size_t)FZ_STREAM_TAB_BYTES + 256u + (size_t)nwaves * W * 64u * stride * 4u;
@@ -769,6 +982,41 @@ static hipError_t launch_stream2(const FzStreamParams &p, hipStream_t st)
     if (p.stride == 37u) return launch_stream3<W, MODE, 37>(p, st);
     if (p.stride == 41u) return launch_stream3<W, MODE, 41>(p, st);
     if (p.stride == 65u) return launch_stream3<W, MODE, 65>(p, st);
+    return hipErrorInvalidValue;
+}
+
+template <int MODE, int STRIDE>
+static hipError_t launch_stream_pk2(const FzStreamParams &p, hipStream_t st)
+{
+    const size_t lds = fz_stream_lds_bytes(1, STRIDE, p.nwaves);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_stream_pk<MODE, STRIDE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint64_t blocks_needed = ((uint64_t)p.nitems + p.nwaves - 1u) / p.nwaves;
+    dim3 grid((uint32_t)(blocks_needed < p.grid_blocks ? blocks_needed : p.grid_blocks));
+    hipLaunchKernelGGL((fz_score_stream_pk<MODE, STRIDE>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_stream_pk(const FzStreamParams &p, hipStream_t st)
+{
+    if (p.stride == 37u) return launch_stream_pk2<MODE, 37>(p, st);
+    if (p.stride == 41u) return launch_stream_pk2<MODE, 41>(p, st);
+    if (p.stride == 65u) return launch_stream_pk2<MODE, 65>(p, st);
+    return hipErrorInvalidValue;
+}
+
+// two tiles per wave: `p.ntiles` tiles of at most 15 symbols, items = (query group, pair of tiles)
+hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st)
+{
+    if (p.nq == 0u || p.ntiles == 0u) return hipSuccess;
+    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u) return hipErrorInvalidValue;
+    if ((uint64_t)((p.ntiles + 1u) / 2u) * ((p.nq + p.q_per_block - 1u) / p.q_per_block) != p.nitems) return hipErrorInvalidValue;
+    if (mode == FZ_MODE_TOKEN_SET) return launch_stream_pk<FZ_MODE_TOKEN_SET>(p, st);
+    if (mode == FZ_MODE_RATIO) return launch_stream_pk<FZ_MODE_RATIO>(p, st);
     return hipErrorInvalidValue;
 }
 
