@@ -75,15 +75,39 @@ def test_token_set_scores_short(oracle, runner, tmp_path, no_stream):
 
 
 def test_packed_short_tiles(oracle, runner, tmp_path):
-    """candidates of at most 15 symbols go to the packed stream kernel, two tiles per wave (7 tiles:
-    the odd last one is scored alone); every streamed scorer against the oracle"""
+    """short candidates go to the packed stream kernel, two tiles per wave (7 tiles: three pairs, the
+    odd one stays with the one-tile kernel); every streamed scorer against the oracle"""
     cps, offs = synth.make_corpus(420, max_chars=14, seed=21, vocab_size=60, max_tokens=4)
     cand = synth.to_strings(cps, offs) + ["", "a", "abcdefghijklmn", "ab cd ef gh", "a b c d"]
     queries = synth.make_queries(cps, offs, 9, seed=22) + ["", cand[5], "zz top", "y" * 70, "a b c d e f",
                                                             cand[17] + " " + cand[40]]
     for sk, orc in ((0, oracle.TOKEN_SET), (1, oracle.RATIO), (2, oracle.TOKEN_SORT)):
         got = _run(runner, tmp_path, 0, sk, cand, queries, env={"FUZZYHIP_TRACE": "1"})
-        assert "7 tiles -> packed 7," in _run.last_stderr, _run.last_stderr[-500:]
+        assert "7 tiles -> packed 6, stream1 1," in _run.last_stderr, _run.last_stderr[-500:]
+        exp = _oracle_scores(oracle, orc, queries, cand)
+        bad = np.argwhere(got != exp)
+        assert bad.size == 0, (sk, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])
+
+
+def test_packed_pairs_of_unequal_tiles(oracle, runner, tmp_path):
+    """tiles sorted by length and paired short with long (split S = longest candidate of the short tile):
+    lengths 0..29 give pairs with many different splits; token_set and ratio against the oracle"""
+    import random
+    rnd = random.Random(41)
+    words = ["".join(rnd.choice("abcdefg") for _ in range(rnd.randint(1, 9))) for _ in range(40)]
+    cand = []
+    for _ in range(700):
+        toks, target = [], rnd.randint(0, 29)
+        while len(toks) < 4:
+            w = rnd.choice(words)
+            if len(" ".join(toks + [w])) > target: break
+            toks.append(w)
+        cand.append(" ".join(toks))
+    queries = [cand[3], cand[500], "abc de", "gfedcba abc", "", " ".join(words[:4]), words[7] + " " + words[8] + " zz"]
+    for sk, orc in ((0, oracle.TOKEN_SET), (1, oracle.RATIO)):
+        got = _run(runner, tmp_path, 0, sk, cand, queries, env={"FUZZYHIP_TRACE": "1"})
+        packed = int(_run.last_stderr.split("-> packed ")[1].split(",")[0])
+        assert packed >= 8, _run.last_stderr[-300:]
         exp = _oracle_scores(oracle, orc, queries, cand)
         bad = np.argwhere(got != exp)
         assert bad.size == 0, (sk, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])

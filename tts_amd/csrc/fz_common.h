@@ -80,7 +80,8 @@ struct FzScoreParams {
 //           which the separator step follows (token_set only).  Symbols no candidate uses are
 //           dropped on the host: they cannot change the LCS state.
 #define FZ_STREAM_MAX_TOK 8u      // token slots of an eligible tile
-#define FZ_PK_MAX_TOK 4u          // ... of a tile the packed kernel takes (<= 15 symbols, two tiles per wave)
+#define FZ_PK_MAX_TOK 4u          // ... of a tile the packed kernel takes (two tiles per wave, <= 31 symbols together)
+#define FZ_PK_SPLIT_SHIFT 27u     // packed tile list: entry 2i = tile A | split << 27, entry 2i + 1 = tile B
 #define FZ_STREAM_MAX_ROWS 63u    // Peq rows (distinct text symbols of one launch), row byte = 4*row < 256
 #define FZ_STREAM_QUEUES 32u      // work queues of one launch (each a contiguous range of items)
 #define FZ_STREAM_QPAD 64u        // u32 words between two queue counters (256 B: one counter per cache line)

@@ -260,10 +260,33 @@ static int upload_tile_lists(View &v, const std::vector<FzTile> &tiles, const st
 {
     std::vector<uint32_t> ts0, ts1, ts2, tslow;
     const bool pack = getenv("FUZZYHIP_NO_PACK") == nullptr;      // experiments: keep short tiles in the plain kernel
+    // Packed pairs: two tiles whose longest candidates have 31 symbols or fewer TOGETHER share one
+    // pattern word per lane (tile A below the split, tile B above it).  Tiles are sorted by their longest
+    // candidate and the shortest is paired with the longest that still fits; a tile that finds no
+    // partner stays with the one-tile kernel.
+    std::vector<uint8_t> paired(v.ntiles, 0);
+    if (pack && !v.wide && v.ntiles < (1u << FZ_PK_SPLIT_SHIFT)) {
+        std::vector<uint32_t> el;
+        for (uint32_t t = 0; t < v.ntiles; ++t)
+            if (tiles[t].ntok <= FZ_PK_MAX_TOK && tile_maxlen[t] <= 29u) el.push_back(t);
+        std::stable_sort(el.begin(), el.end(), [&](uint32_t a, uint32_t b) { return tile_maxlen[a] < tile_maxlen[b]; });
+        size_t lo = 0, hi = el.size();
+        while (lo + 1 < hi) {
+            const uint32_t a = el[lo], b = el[hi - 1];
+            if (tile_maxlen[a] + tile_maxlen[b] <= 31u) {
+                ts0.push_back(a | (tile_maxlen[a] << FZ_PK_SPLIT_SHIFT));      // split = field width of tile A
+                ts0.push_back(b);
+                paired[a] = paired[b] = 1;
+                ++lo; --hi;
+            } else {
+                --hi;                                                         // too long for any partner left
+            }
+        }
+    }
     for (uint32_t t = 0; t < v.ntiles; ++t) {
         // the stream kernel keeps one Peq row per symbol byte: 8-bit symbols only
-        if (pack && !v.wide && tiles[t].ntok <= FZ_PK_MAX_TOK && tile_maxlen[t] <= 15u) ts0.push_back(t);
-        else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
+        if (paired[t]) continue;
+        if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
         else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
         else tslow.push_back(t);
     }
@@ -280,7 +303,7 @@ static int upload_tile_lists(View &v, const std::vector<FzTile> &tiles, const st
 }
 
 // Builds one device view: reduce every candidate to the text its scorer compares, map code points
-// to 8-bit symbols, sort by (symbol dwords, tokens, original index), cut into 64-candidate tiles,
+// to 8-bit symbols, sort by (length, tokens, original index), cut into 64-candidate tiles,
 // transpose to symbol-major order and upload.
 static int build_view(fz_corpus *c, int kind)
 {
@@ -366,8 +389,10 @@ static int build_view(fz_corpus *c, int kind)
     v.npad = v.ntiles * FZ_TILE;
     std::vector<uint64_t> keys(n);
     for (uint64_t i = 0; i < n; ++i) {
-        uint64_t ndw = (canon_off[i + 1] - canon_off[i] + spd - 1) / spd, nt = tok_off[i + 1] - tok_off[i];
-        keys[i] = (ndw << 48) | (std::min<uint64_t>(nt, 0xFFFF) << 32) | i;
+        // by exact length (so that a tile's longest candidate is close to its shortest: the packed
+        // kernel pairs tiles by that length), then token slots, then original index
+        uint64_t len = canon_off[i + 1] - canon_off[i], nt = tok_off[i + 1] - tok_off[i];
+        keys[i] = (len << 48) | (std::min<uint64_t>(nt, 0xFFFF) << 32) | i;
     }
     std::sort(keys.begin(), keys.end());
     v.h_orig_of_phys.assign(v.npad, 0xFFFFFFFFu);
@@ -1093,7 +1118,7 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
             const int W = cls == 2 ? 2 : 1;
             const uint32_t nt = cls == 0 ? v.n_s0 : (cls == 1 ? v.n_s1 : v.n_s2);
             if (nt == 0) continue;
-            const uint32_t units = cls == 0 ? (nt + 1u) / 2u : nt;      // tiles (or tile pairs) to hand out
+            const uint32_t units = cls == 0 ? nt / 2u : nt;             // tiles (or tile pairs) to hand out
             FzStreamParams p{};
             p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
             p.tile_list = cls == 0 ? v.d_tiles_s0 : (cls == 1 ? v.d_tiles_s1 : v.d_tiles_s2);

@@ -745,13 +745,14 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
 // ---------------------------------------------------------------------------------------------
 // packed stream kernel: TWO short candidates per lane in one 32-bit pattern word
 // ---------------------------------------------------------------------------------------------
-// Tiles whose candidates have at most 15 symbols are taken two at a time: tile A lives in bits 0..14
-// of every pattern word of the lane, tile B in bits 16..30.  One LDS row read and one Hyyro update
-// then serve two candidates.  Bit 15 is the carry stopper: it is 1 in V and 0 in every match mask, and
-// it is cleared in the addend, so the carry chain of A ends there (bit 15 of the sum is dropped by the
-// OR with V ^ u, whose bit 15 is always 1) and never reaches B; the carry out of bit 31 is discarded by
-// the 32-bit add.  Everything else is the stream kernel above, with the per-candidate pieces doubled.
-#define FZ_PK_FIELD 0x7FFFu
+// Two tiles whose longest candidates have S and at most 31 - S symbols are taken together: tile A lives
+// in bits 0..S-1 of every pattern word of the lane, tile B in bits S+1..31 (the host pairs short tiles
+// with long ones and passes S with the pair).  One LDS row read and one Hyyro update then serve two
+// candidates.  Bit S is the carry stopper: it is 1 in V and 0 in every match mask, and it is cleared in
+// the addend, so the carry chain of A ends there (bit S of the sum is dropped by the OR with V ^ u, whose
+// bit S is always 1) and never reaches B; the carry out of bit 31 is discarded by the 32-bit add.  Bits
+// of a field beyond its candidate stay 1 in V and in M, so they count neither as matches nor as common
+// tokens.  Everything else is the stream kernel above, with the per-candidate pieces doubled.
 
 template <int MODE, int STRIDE, int NT>
 __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, const FzRec *__restrict__ recs,
@@ -759,7 +760,7 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
                                                      uint32_t col_off, const uint32_t (&cid)[2][FZ_PK_MAX_TOK],
                                                      const uint32_t (&Rm)[2][FZ_PK_MAX_TOK], uint32_t psep,
                                                      const uint32_t (&clen)[2], const uint32_t (&out_off)[2],
-                                                     uint32_t qgroup)
+                                                     const uint32_t (&fmask)[2], uint32_t nstop, uint32_t qgroup)
 {
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
@@ -776,6 +777,7 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
         if (MODE == FZ_MODE_TOKEN_SET) {
             // a candidate token the query also has leaves the pattern: its range is cleared in M at once
             // (no per-token lane masks to carry through the loop: sixteen of them would not fit the SGPRs)
+#pragma nounroll                                       // unrolled, its compare masks spill (52 bytes of scratch)
             for (uint32_t j = 0; j < n_ids; j += 4u) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -808,13 +810,13 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
 #pragma unroll
                         for (int i = 0; i < NT; ++i) skip[h] |= cid[h][i] == id;
                 }
-                Mk = M & (skip[0] ? 0xFFFF0000u : 0xFFFFFFFFu) & (skip[1] ? 0x0000FFFFu : 0xFFFFFFFFu);
+                Mk = M & (skip[0] ? ~fmask[0] : 0xFFFFFFFFu) & (skip[1] ? ~fmask[1] : 0xFFFFFFFFu);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(row[k]) : : "memory");
             FZ_ADVANCE();
 #define FZ_PK_STEP(rw) do { const uint32_t v_ = V; const uint32_t u_ = __builtin_amdgcn_bitop3_b32(v_, (rw), Mk, 0x80); \
-                            V = __builtin_amdgcn_bitop3_b32((v_ & 0xFFFF7FFFu) + u_, v_, u_, 0xF6); } while (0)
+                            V = __builtin_amdgcn_bitop3_b32((v_ & nstop) + u_, v_, u_, 0xF6); } while (0)
             if (nsym > 0u) { FZ_PK_STEP(row[0]);
             if (nsym > 1u) { FZ_PK_STEP(row[1]);
             if (nsym > 2u) { FZ_PK_STEP(row[2]);
@@ -830,10 +832,10 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
         uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint32_t lcs = (uint32_t)__builtin_popcount((~V >> (16 * h)) & FZ_PK_FIELD);
+            const uint32_t lcs = (uint32_t)__builtin_popcount(~V & fmask[h]);
             uint32_t sc;
             if (MODE == FZ_MODE_TOKEN_SET) {
-                const uint32_t sect1 = (uint32_t)__builtin_popcount((~M >> (16 * h)) & FZ_PK_FIELD);
+                const uint32_t sect1 = (uint32_t)__builtin_popcount(~M & fmask[h]);
                 const uint32_t mc = m + clen[h];
                 const uint32_t d0 = mc - 2u * (sect1 + lcs);
                 const uint32_t r0 = s_tab[(((mc - 2u) << 6) + (d0 >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
@@ -903,11 +905,15 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
         // ---- candidate side: two tiles, once per item --------------------------------------------
         for (uint32_t r = 0; r < (uint32_t)STRIDE; ++r) *reinterpret_cast<uint32_t *>(col + r * 4u) = 0u;
         uint32_t cid[2][FZ_PK_MAX_TOK], Rm[2][FZ_PK_MAX_TOK], clen[2], out_off[2], psep = 0u, ntok = 0u;
+        // entry 2*pair carries the split S above the tile index: field A = bits [0, S), B = bits [S + 1, 32)
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.tile_list[2u * pair]);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.tile_list[2u * pair + 1u]);
+        const uint32_t S = e0 >> FZ_PK_SPLIT_SHIFT;
+        const uint32_t sh[2] = {0u, S + 1u}, fw[2] = {S, 31u - S};
+        const uint32_t fmask[2] = {(1u << S) - 1u, 0xFFFFFFFFu << (S + 1u)};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            // an odd tile count: the last item scores its one tile in both halves (same values, same addresses)
-            const uint32_t tix = 2u * pair + (uint32_t)h < p.ntiles ? 2u * pair + (uint32_t)h : 2u * pair;
-            const uint32_t tile = p.tile_list[tix];
+            const uint32_t tile = (h == 0 ? e0 : e1) & ((1u << FZ_PK_SPLIT_SHIFT) - 1u);
             const FzTile td = p.tiles[tile];
             out_off[h] = tile * 64u + lane;
             if (td.ntok > ntok) ntok = td.ntok;
@@ -920,20 +926,20 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
                     if (MODE == FZ_MODE_TOKEN_SET) cid[h][i] = p.tokid[td.toff + (uint32_t)i * 64u + lane];
                     end = p.tokend[td.toff + (uint32_t)i * 64u + lane];
                 }
-                if (end > 15u) end = 15u;                                // host guarantee; keeps the shifts defined
-                Rm[h][i] = (((1u << end) - 1u) & ~((1u << prev_end) - 1u)) << (16 * h);   // pattern positions of token i
+                if (end > fw[h]) end = fw[h];                            // host guarantee; keeps the shifts defined
+                Rm[h][i] = (((1u << end) - 1u) & ~((1u << prev_end) - 1u)) << sh[h];       // pattern positions of token i
                 prev_end = end;
             }
             clen[h] = prev_end;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
+            for (int d = 0; d < 8; ++d) {
                 if ((uint32_t)d < td.ndw) {
                     const uint32_t cw = p.sym[td.coff + (uint32_t)d * 64u + lane];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const uint32_t s = (cw >> (8 * k)) & 0xFFu;
-                        if (d * 4 + k < 15) {
-                            const uint32_t bit = 1u << (d * 4 + k + 16 * h);
+                        if ((uint32_t)(d * 4 + k) < fw[h]) {
+                            const uint32_t bit = 1u << ((uint32_t)(d * 4 + k) + sh[h]);
                             if (MODE == FZ_MODE_TOKEN_SET && s == FZ_SYM_SPACE) {
                                 psep |= bit;
                             } else {
@@ -948,10 +954,10 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
             }
         }
         ntok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ntok);
-        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
-        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, ~(1u << S), qgroup);
+        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, ~(1u << S), qgroup);
+        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, ~(1u << S), qgroup);
+        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, ~(1u << S), qgroup);
     }
 }
 
@@ -1009,12 +1015,12 @@ static hipError_t launch_stream_pk(const FzStreamParams &p, hipStream_t st)
     return hipErrorInvalidValue;
 }
 
-// two tiles per wave: `p.ntiles` tiles of at most 15 symbols, items = (query group, pair of tiles)
+// two tiles per wave: `p.ntiles` tiles in pairs (entry 2i carries the split of pair i), items = (query group, pair)
 hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st)
 {
     if (p.nq == 0u || p.ntiles == 0u) return hipSuccess;
     if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u) return hipErrorInvalidValue;
-    if ((uint64_t)((p.ntiles + 1u) / 2u) * ((p.nq + p.q_per_block - 1u) / p.q_per_block) != p.nitems) return hipErrorInvalidValue;
+    if ((p.ntiles & 1u) || (uint64_t)(p.ntiles / 2u) * ((p.nq + p.q_per_block - 1u) / p.q_per_block) != p.nitems) return hipErrorInvalidValue;
     if (mode == FZ_MODE_TOKEN_SET) return launch_stream_pk<FZ_MODE_TOKEN_SET>(p, st);
     if (mode == FZ_MODE_RATIO) return launch_stream_pk<FZ_MODE_RATIO>(p, st);
     return hipErrorInvalidValue;
