@@ -151,7 +151,7 @@ struct fz_corpus {
     bool use_stream = true;                               // FUZZYHIP_NO_STREAM=1 forces the general kernel
     uint32_t stream_oversub = 1;                          // FUZZYHIP_STREAM_OVERSUB: persistent blocks per slot
     uint32_t pipe_chunks = 1;                             // FUZZYHIP_CHUNKS: pieces of a large top-k batch
-    uint32_t stream_waves = 16, stream_blocks = 8192;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
+    uint32_t stream_waves = 16, stream_blocks = 3072;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
     std::vector<hipEvent_t> events;
     fz_timing timing{};
     std::mutex mu;
