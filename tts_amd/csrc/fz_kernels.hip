@@ -486,6 +486,24 @@ __device__ __forceinline__ uint32_t fz_lds_load(uint32_t addr)
     return *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)addr;     // EMUL: return *(const uint32_t *)(emul::g_lds + addr);
 }
 
+// a + b + c in ONE lane operation with c in a scalar register (left to itself the compiler hoists a + c
+// out of the dependency chain as a second instruction)
+__device__ __forceinline__ uint32_t fz_add3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));   // EMUL: r = a + b + c;
+    return r;
+}
+
+// a byte of the rounded-score table: index masked to the table and ORed onto its LDS address in one
+// v_and_or (the table is the first thing in LDS, so its address is a multiple of its size: checked once
+// per block by the packed kernel)
+__device__ __forceinline__ uint32_t fz_tab_load(uint32_t tab_off, uint32_t idx)
+{
+    const uint32_t a = (idx & (FZ_STREAM_TAB_BYTES - 1u)) | tab_off;
+    return *(__attribute__((address_space(3))) const uint8_t *)(uintptr_t)a;   // EMUL: return *(const uint8_t *)(emul::g_lds + a);
+}
+
 template <int W, int STRIDE>
 __device__ __forceinline__ void fz_stream_step(uint32_t (&V)[W], const uint32_t (&row)[W], const uint32_t (&Mk)[W])
 {
@@ -760,8 +778,23 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
                                                      uint32_t col_off, const uint32_t (&cid)[2][FZ_PK_MAX_TOK],
                                                      const uint32_t (&Rm)[2][FZ_PK_MAX_TOK], uint32_t psep,
                                                      const uint32_t (&clen)[2], const uint32_t (&out_off)[2],
-                                                     const uint32_t (&fmask)[2], uint32_t nstop, uint32_t qgroup)
+                                                     const uint32_t (&fmask)[2], const uint32_t (&fw)[2], uint32_t negstop,
+                                                     uint32_t qgroup)
 {
+    // Lane constants of the score look-ups (end of the query loop).  With bm = popcount(M & field) and
+    // bv = popcount(V & field): sect1 = fw - bm, lcs = fw - bv, and (m + clen) >> 1 = (m >> 1) + (clen >> 1)
+    // + (m & clen & 1), so every table index is a per-tile lane constant + a per-query scalar + popcounts.
+    // The empty asm keeps the constants as they are (the compiler would re-derive them per query).
+    const uint32_t tab_off = fz_lds_addr(s_tab);
+    uint32_t c_tab[2], c_odd[2], c_len1[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        c_tab[h] = MODE == FZ_MODE_TOKEN_SET ? ((clen[h] - 2u) << 6) + (clen[h] >> 1) - 2u * fw[h]
+                                             : (clen[h] << 6) + (clen[h] >> 1) - fw[h];
+        c_odd[h] = clen[h] & 1u;
+        c_len1[h] = clen[h] + fw[h] - 2u;
+        asm volatile("" : "+v"(c_tab[h]), "+v"(c_odd[h]), "+v"(c_len1[h]));
+    }
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
     uint32_t ri = p.qrec[q0];
@@ -816,7 +849,7 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
             for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(row[k]) : : "memory");
             FZ_ADVANCE();
 #define FZ_PK_STEP(rw) do { const uint32_t v_ = V; const uint32_t u_ = __builtin_amdgcn_bitop3_b32(v_, (rw), Mk, 0x80); \
-                            V = __builtin_amdgcn_bitop3_b32((v_ & nstop) + u_, v_, u_, 0xF6); } while (0)
+                            V = __builtin_amdgcn_bitop3_b32(fz_add3(v_, u_, negstop), v_, u_, 0xF6); } while (0)
             if (nsym > 0u) { FZ_PK_STEP(row[0]);
             if (nsym > 1u) { FZ_PK_STEP(row[1]);
             if (nsym > 2u) { FZ_PK_STEP(row[2]);
@@ -830,22 +863,28 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
         }
 
         uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
+        const uint32_t qs = (m << 6) + (m >> 1), m_odd = 0u - (m & 1u);          // scalars
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint32_t lcs = (uint32_t)__builtin_popcount(~V & fmask[h]);
+            const uint32_t bv = (uint32_t)__builtin_popcount(V & fmask[h]);
+            const uint32_t both_odd = c_odd[h] & m_odd;
             uint32_t sc;
             if (MODE == FZ_MODE_TOKEN_SET) {
-                const uint32_t sect1 = (uint32_t)__builtin_popcount(~M & fmask[h]);
-                const uint32_t mc = m + clen[h];
-                const uint32_t d0 = mc - 2u * (sect1 + lcs);
-                const uint32_t r0 = s_tab[(((mc - 2u) << 6) + (d0 >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
-                const uint32_t d1 = (m < clen[h] ? m : clen[h]) - sect1;
-                const uint32_t r1 = s_tab[(((2u * sect1 - 2u + d1) << 6) + (d1 >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
-                sc = (sect1 != 0u && r1 > r0) ? r1 : r0;
+                //   r0 = T[m + clen - 2][(m + clen - 2*(sect1 + lcs)) >> 1]      (the joined differences)
+                //   r1 = T[sect1 + mn - 2][(mn - sect1) >> 1], mn = min(m, clen)  (intersection vs intersection +
+                //        shorter difference; 100 when one side is contained in the other), used when sect1 > 0
+                const uint32_t bm = (uint32_t)__builtin_popcount(M & fmask[h]);
+                uint32_t r0 = fz_tab_load(tab_off, c_tab[h] + both_odd + qs + bm + bv);
+                const uint32_t m1 = m + fw[h] - 2u;                                      // scalar
+                const uint32_t mn1 = m1 < c_len1[h] ? m1 : c_len1[h];                    // mn + fw - 2
+                const uint32_t d1 = mn1 + bm - (2u * fw[h] - 2u);                        // mn - sect1
+                uint32_t r1 = fz_tab_load(tab_off, ((mn1 - bm) << 6) + (d1 >> 1));
+                asm volatile("" : "+v"(r0), "+v"(r1));               // plain 32-bit values (no 16-bit max + re-mask)
+                sc = (bm != fw[h] && r1 > r0) ? r1 : r0;
                 if (clen[h] == 0u) sc = 0u;                           // a candidate without tokens scores 0
             } else {
-                const uint32_t L = m + clen[h];
-                sc = s_tab[((L << 6) + ((L - 2u * lcs) >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];
+                // T[L][(L - 2*lcs) >> 1] with L = m + clen
+                sc = fz_tab_load(tab_off, c_tab[h] + both_odd + qs + bv);
             }
             rowp[out_off[h]] = (uint8_t)sc;
         }
@@ -868,6 +907,7 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
     for (uint32_t i = tid; i < FZ_STREAM_TAB_BYTES / 16u; i += blockDim.x)
         reinterpret_cast<uint4 *>(s_tab)[i] = reinterpret_cast<const uint4 *>(p.score_tab)[i];
     if (tid < 64u) reinterpret_cast<uint32_t *>(s_row)[tid] = reinterpret_cast<const uint32_t *>(p.row_of_sym)[tid];
+    if (fz_lds_addr(s_tab) & (FZ_STREAM_TAB_BYTES - 1u)) __builtin_trap();    // fz_tab_load ORs indices onto this address
     __syncthreads();                                                     // the only block-wide barrier
 
     uint8_t *col = s_peq + wave * PLANE + lane * ((uint32_t)STRIDE * 4u);   // this lane's column
@@ -954,10 +994,10 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
             }
         }
         ntok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ntok);
-        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, ~(1u << S), qgroup);
-        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, ~(1u << S), qgroup);
-        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, ~(1u << S), qgroup);
-        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, ~(1u << S), qgroup);
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), qgroup);
+        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), qgroup);
+        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), qgroup);
+        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), qgroup);
     }
 }
 
