@@ -1186,8 +1186,16 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
     // and tests a dword with one SWAR expression before it looks at its bytes: with t in 1..128,
     // ((x + 0x01010101 * (128 - t)) | x) & 0x80808080 is non-zero iff some byte of x is >= t (a carry
     // out of a byte >= 128 can only add false positives; the byte loop below is exact).
+    // Pass B reads again only what can matter: `seen` has one bit per vector of this thread, set when the
+    // vector held a byte >= the bound of its time.  That bound only rises and never exceeds pass B's own
+    // filter (tlow <= sstar, or sstar + 1 once the ties at sstar are past sorting, and then pass B filters
+    // at sstar + 1 as well), so an unmarked vector holds nothing pass B would take.  After the first
+    // update of the bound (two iterations) almost no vector is marked.  Rows of more than 64 vectors per
+    // thread (> 2^20 candidates) are read in full.
     const uint32_t per_iter = SEL_THREADS * 16u * SEL_VEC;
     const uint32_t niter = (n + per_iter - 1u) / per_iter;
+    const bool track = niter * SEL_VEC <= 64u;
+    uint64_t seen = 0ull;
     for (uint32_t it = 0; it < niter; ++it) {
         const uint32_t tlow = s_misc[8];                     // count scores >= this (<= 101)
         const uint32_t add = 0x01010101u * (128u - (tlow ? tlow : 1u));
@@ -1201,10 +1209,12 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
         for (uint32_t j = 0; j < SEL_VEC; ++j) {
             const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
             const uint32_t wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            uint32_t any = 0u;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 // one flag bit (7, 15, 23, 31) per candidate byte; the lane then visits only those bytes
                 uint32_t m = tlow != 0u ? (((wv[a] + add) | wv[a]) & 0x80808080u) : 0x80808080u;
+                any |= m;
                 while (__ballot(m != 0u) != 0ull) {                      // wave-uniform trip count
                     const bool on = m != 0u;
                     const uint32_t sh = on ? (uint32_t)__builtin_ctz(m) - 7u : 0u;
@@ -1214,6 +1224,7 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
                     fz_hist_add(s_hist, s, on && s >= tlow && s <= 100u && base + (uint32_t)(4 * a) + (sh >> 3) < n);
                 }
             }
+            if (track && any != 0u) seen |= 1ull << (it * SEL_VEC + j);
         }
         if ((it & 1u) == 1u) fz_sel_update(s_hist, s_cum, s_misc, k);
     }
@@ -1237,7 +1248,8 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
 #pragma unroll
             for (uint32_t j = 0; j < SEL_VEC; ++j) {
                 const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
-                v[j] = base < n ? *reinterpret_cast<const uint4 *>(sc + base) : uint4{0u, 0u, 0u, 0u};
+                const bool want = !track || ((seen >> (it * SEL_VEC + j)) & 1ull) != 0ull;
+                v[j] = (base < n && want) ? *reinterpret_cast<const uint4 *>(sc + base) : uint4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
             for (uint32_t j = 0; j < SEL_VEC; ++j) {
