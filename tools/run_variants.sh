@@ -4,7 +4,7 @@ O=gpurun_out; T=${1:-var}; shift
 cp tts_amd/libfuzzyhip.so /tmp/lib_orig.so
 for v in "$@"; do
   cp variants/var_$v/libfuzzyhip.so tts_amd/libfuzzyhip.so
-  for e in "" "FUZZYHIP_NO_PACK=1"; do
+  for e in ""; do
     env $e timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --latency-reps 0 > $O/${T}_$v.json 2> $O/${T}_$v.err
     python -c "
 import json,sys
