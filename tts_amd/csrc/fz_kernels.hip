@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
             }
             if (track && any != 0u) seen |= 1ull << (it * SEL_VEC + j);
         }
-        if ((it & 1u) == 1u) fz_sel_update(s_hist, s_cum, s_misc, k);
+        if (it == 0u || (it & 1u) == 1u) fz_sel_update(s_hist, s_cum, s_misc, k);   // early first update: the bound rises after 64 Ki candidates
     }
     fz_sel_update(s_hist, s_cum, s_misc, k);
 
