@@ -1085,6 +1085,7 @@ hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_
 #define SEL_WAVES (SEL_THREADS / 64u)
 #define SEL16_THREADS 256u     // fz_select16_topk: one thread per histogram bin
 #define SEL_TIECAP 2048u
+#define SEL_PICK_MAX 16u      // up to this many ties are picked by repeated minima instead of a sort
 #define SEL_VEC 4u            // 16-byte vectors per thread per iteration of the row passes
 
 __device__ __forceinline__ uint64_t fz_local_key(uint32_t score, uint32_t orig)
@@ -1166,6 +1167,7 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
 {
     __shared__ uint32_t s_hist[128];
     __shared__ uint32_t s_cum[129];
+    __shared__ uint64_t s_pick[SEL_WAVES];
     __shared__ uint32_t s_misc[16 + SEL_WAVES];   // 0: tlow  1: scratch  2: n_gt  3: n_tie  8: count filter  16..: wave counts
     __shared__ uint64_t s_keys[FZ_MAX_K];
     __shared__ uint32_t s_ties[SEL_TIECAP];
@@ -1284,7 +1286,33 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
     // ---- ties at the cut: the `need` smallest original indices ------------------------------
     if (need > 0u) {
         if (few_ties) {
-            if (need < c_eq) {
+            if (need < c_eq && need <= SEL_PICK_MAX) {
+                // a few out of many (top-10 under a thousand ties): `need` block-wide minima instead of a
+                // sort of all ties.  Round r moves the smallest of s_ties[r, c_eq) to position r; original
+                // indices are distinct, so (index << 32 | position) has one minimum.
+                for (uint32_t r = 0; r < need; ++r) {
+                    uint64_t best = ~0ull;
+                    for (uint32_t i = r + tid; i < c_eq; i += blockDim.x) {
+                        const uint64_t key = ((uint64_t)s_ties[i] << 32) | i;
+                        if (key < best) best = key;
+                    }
+                    for (uint32_t off = 32u; off > 0u; off >>= 1) {
+                        const uint32_t hi = __shfl_down((uint32_t)(best >> 32), off, 64), lo = __shfl_down((uint32_t)best, off, 64);
+                        const uint64_t other = ((uint64_t)hi << 32) | lo;
+                        if (lane + off < 64u && other < best) best = other;
+                    }
+                    if (lane == 0u) s_pick[wave] = best;
+                    __syncthreads();
+                    if (tid == 0u) {
+                        uint64_t m = s_pick[0];
+                        for (uint32_t w = 1; w < SEL_WAVES; ++w) if (s_pick[w] < m) m = s_pick[w];
+                        const uint32_t pos = (uint32_t)m;
+                        s_ties[pos] = s_ties[r];
+                        s_ties[r] = (uint32_t)(m >> 32);
+                    }
+                    __syncthreads();
+                }
+            } else if (need < c_eq) {
                 uint32_t P = 2u;
                 while (P < c_eq) P <<= 1;
                 for (uint32_t i = c_eq + tid; i < P; i += blockDim.x) s_ties[i] = 0xFFFFFFFFu;
