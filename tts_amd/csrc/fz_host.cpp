@@ -137,6 +137,9 @@ struct fz_corpus {
 
     // query-time state
     hipStream_t stream = nullptr, own_stream = nullptr;
+    hipStream_t aux_stream[2] = {nullptr, nullptr};        // the stream kernels of one call run side by side (FUZZYHIP_NO_OVERLAP=1: one after the other)
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool overlap = true;
     uint64_t ws_limit = 4ull << 30;
     uint8_t *d_scores = nullptr; size_t scores_cap = 0;
     uint8_t *d_qbuf = nullptr; size_t qbuf_cap = 0;
@@ -252,6 +255,8 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    for (hipStream_t a : c->aux_stream) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+    for (hipEvent_t e : {c->ev_fork, c->ev_join[0], c->ev_join[1]}) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -517,6 +522,10 @@ static int finish_create(fz_corpus *c)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     c->stream = c->own_stream;
+    if (const char *ev = getenv("FUZZYHIP_NO_OVERLAP")) c->overlap = !(ev[0] == '1');
+    for (int i = 0; i < 2 && c->overlap; ++i)
+        if (hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_join[i]) != hipSuccess) c->overlap = false;
+    if (c->overlap && hipEventCreate(&c->ev_fork) != hipSuccess) c->overlap = false;
     return FZ_OK;
 }
 
@@ -1114,10 +1123,23 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
         // odd strides keep the 64 lane columns on distinct banks; the smallest one that holds the rows of
         // this launch leaves room for the most waves (37: a-z, 0-9 and one spare)
         const uint32_t stride = b.nrows <= 37u ? 37u : (b.nrows <= 41u ? 41u : 65u);
+        // The (up to) three stream kernels write disjoint columns of the score matrix and each ends in a
+        // tail where CUs that have drained their queue idle: they go to three streams, forked after the
+        // upload and joined before anything reads the scores, so that one kernel's blocks start on the CUs
+        // another one's tail frees.
+        const bool side_by_side = c->overlap && ((v.n_s0 != 0) + (v.n_s1 != 0) + (v.n_s2 != 0)) > 1;
+        if (side_by_side) {
+            HIP_TRY(hipEventRecord(c->ev_fork, st));
+            for (hipStream_t a : c->aux_stream) HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+        }
+        int n_aux = 0, n_launched = 0;
+        bool used_aux[2] = {false, false};
         for (int cls = 0; cls <= 2; ++cls) {           // 0: packed pairs of short tiles, 1 / 2: pattern words
             const int W = cls == 2 ? 2 : 1;
             const uint32_t nt = cls == 0 ? v.n_s0 : (cls == 1 ? v.n_s1 : v.n_s2);
             if (nt == 0) continue;
+            hipStream_t lst = st;                      // the first kernel stays on the caller's stream
+            if (side_by_side && n_launched > 0) { lst = c->aux_stream[n_aux]; used_aux[n_aux] = true; ++n_aux; }
             const uint32_t units = cls == 0 ? nt / 2u : nt;             // tiles (or tile pairs) to hand out
             FzStreamParams p{};
             p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
@@ -1142,16 +1164,22 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
             const uint64_t waves_total = (uint64_t)p.grid_blocks * p.nwaves;
             p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1u, 32u / p.q_per_block), p.nitems / waves_total));
             p.work_counter = c->d_counters + (size_t)(c->counter_next++ & 63u) * FZ_STREAM_QUEUES * FZ_STREAM_QPAD;
-            HIP_TRY(hipMemsetAsync(p.work_counter, 0, FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(p.work_counter, 0, FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), lst));
             p.row_of_sym = c->d_qbuf + o_rows;
             p.recs = reinterpret_cast<const FzRec *>(c->d_qbuf + o_rec);
             p.qrec = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_qrec);
             p.score_tab = c->d_score_tab[kmode == FZ_MODE_TOKEN_SET ? 0 : 1];
             p.scores = c->d_scores; p.row_stride = (uint32_t)row_stride;
-            if (cls == 0) HIP_TRY(fz_launch_stream_pk(kmode, p, st));
-            else HIP_TRY(fz_launch_stream(W, kmode, p, st));
+            if (cls == 0) HIP_TRY(fz_launch_stream_pk(kmode, p, lst));
+            else HIP_TRY(fz_launch_stream(W, kmode, p, lst));
             c->timing.score_launches++;
+            ++n_launched;
         }
+        for (int i = 0; i < 2; ++i)
+            if (used_aux[i]) {
+                HIP_TRY(hipEventRecord(c->ev_join[i], c->aux_stream[i]));
+                HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
+            }
     }
     return FZ_OK;
 }
