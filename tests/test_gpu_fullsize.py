@@ -1,0 +1,132 @@
+"""GPU parity AT BASELINE.json's sizes: the packed/paired tile layout, the persistent work queues and
+the slab/sample schedules only exist at size, so the score matrix and the top-k of a few queries are
+compared with the oracle over the FULL corpora (reference loop: src/fuzzy_search.py:22-38).
+
+The oracle's scorer loop runs on the box's host threads (ctypes releases the GIL); its bit-parallel
+LCS is used here for speed -- tests/test_oracle.py checks it against the DP."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tts_amd import Corpus, _lib, synth  # noqa: E402
+from tts_amd.preprocess import prepare  # noqa: E402
+
+THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+@pytest.fixture()
+def fast_oracle(oracle):
+    oracle.lib().orc_set_bitpar(1)
+    yield oracle
+    oracle.lib().orc_set_bitpar(0)
+
+
+def _oracle_matrix(oracle, scorer, queries, buf, offs, n, pieces=THREADS):
+    """score_all of every query, the candidate range cut into `pieces` for the thread pool"""
+    bounds = np.linspace(0, n, pieces + 1).astype(np.int64)
+    out = np.zeros((len(queries), n), dtype=np.uint8)
+
+    def work(job):
+        qi, lo, hi = job
+        sub = np.ascontiguousarray(offs[lo:hi + 1])
+        out[qi, lo:hi] = oracle.score_all(scorer, queries[qi], buf, sub).astype(np.uint8)
+
+    jobs = [(qi, int(bounds[p]), int(bounds[p + 1])) for qi in range(len(queries)) for p in range(pieces)
+            if bounds[p + 1] > bounds[p]]
+    with ThreadPoolExecutor(THREADS) as ex:
+        list(ex.map(work, jobs))
+    return out
+
+
+def _topk_from_matrix(row, min_score, k):
+    """the reference's filter + stable sort(reverse=True) + slice on one row of integer scores"""
+    idx = np.nonzero(row >= min_score)[0]
+    order = np.argsort(-row[idx].astype(np.int64), kind="stable")[:k]
+    return [(int(idx[j]), int(row[idx[j]])) for j in order]
+
+
+def _assert_same(got, exp, queries, cps, offs):
+    bad = np.argwhere(got != exp)
+    if bad.size:
+        msg = []
+        for q, i in bad[:5]:
+            cand = "".join(map(chr, cps[int(offs[i]):int(offs[i + 1])]))
+            msg.append((queries[q][:60], cand[:60], int(got[q, i]), int(exp[q, i])))
+        raise AssertionError(f"{bad.shape[0]} mismatches, first: {msg}")
+
+
+def test_c2_full_corpus_vs_oracle(fast_oracle):
+    """C2: the bench corpus itself (10^6 names <= 64 chars, bench.py's seeds): 8 queries incl. a one-token
+    query (massive ties at 100) and an exact name; score matrix and top-k against the oracle."""
+    n = 1_000_000
+    cps, offs = synth.make_corpus(n, max_chars=64)
+    names = synth.to_strings(cps, offs, 0, 64)
+    queries = synth.make_queries(cps, offs, 5) + [names[3].split()[0], names[17], "zz qq not in any name"]
+    with Corpus(cps, offs) as c:
+        got = c.score_all(queries)
+        exp = _oracle_matrix(fast_oracle, fast_oracle.TOKEN_SET, queries, cps, offs, n)
+        _assert_same(got, exp, queries, cps, offs)
+        for min_score, k in ((35, 10), (100, 64), (0, 1)):
+            idx, score, cnt = c.topk(queries, min_score, k)
+            for qi in range(len(queries)):
+                e = _topk_from_matrix(exp[qi], min_score, k)
+                g = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
+                assert g == e, (queries[qi], min_score, k, g[:4], e[:4])
+
+
+def test_c4_long_strings_vs_oracle(fast_oracle):
+    """C4: 10^5 candidates of 64-512 chars (8-60 tokens), multi-word patterns W = 2..16."""
+    n = 100_000
+    cps, offs = synth.make_corpus(n, max_chars=512, min_tokens=8, max_tokens=60, seed=synth.CORPUS_SEED + 4)
+    queries = synth.make_queries(cps, offs, 3, seed=synth.QUERY_SEED + 4, max_chars=512)
+    queries.append(" ".join(synth.to_strings(cps, offs, 7, 8)[0].split()[:9]))
+    with Corpus(cps, offs) as c:
+        got = c.score_all(queries)
+        exp = _oracle_matrix(fast_oracle, fast_oracle.TOKEN_SET, queries, cps, offs, n)
+        _assert_same(got, exp, queries, cps, offs)
+        idx, score, cnt = c.topk(queries, 35, 10)
+        for qi in range(len(queries)):
+            e = _topk_from_matrix(exp[qi], 35, 10)
+            assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == e, queries[qi][:60]
+
+
+def test_c5_unicode_all_scorers_vs_oracle(fast_oracle):
+    """C5: 10^5 mixed-case names with Latin-1, Arabic and punctuation through the reference
+    preprocessing; token_set, token_sort, ratio and partial on 4 queries."""
+    from test_gpu_scorers import _unicode_corpus
+    raw = _unicode_corpus(100_000, 77)
+    cand = [prepare(s) for s in raw]
+    queries = [prepare(q) for q in ("COKE-ZERO 330ml", "مياه معدنية ٥٠٠", "Café Crème (PET)", "fathima grocery & sons l.l.c")]
+    buf, o = fast_oracle.pack(cand)
+    n = len(cand)
+    with Corpus.from_prepared(cand) as c:
+        for sc, orc in ((_lib.TOKEN_SET, fast_oracle.TOKEN_SET), (_lib.TOKEN_SORT, fast_oracle.TOKEN_SORT),
+                        (_lib.RATIO, fast_oracle.RATIO), (_lib.PARTIAL, fast_oracle.PARTIAL)):
+            got = c.score_all(queries, sc)
+            exp = _oracle_matrix(fast_oracle, orc, queries, buf, o, n)
+            _assert_same(got, exp, queries, buf, o)
+            idx, score, cnt = c.topk(queries, 50, 10, sc)
+            for qi in range(len(queries)):
+                e = _topk_from_matrix(exp[qi], 50, 10)
+                assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == e, (sc, queries[qi])
+
+
+def test_more_than_65535_queries_general_kernel(fast_oracle):
+    """A batch beyond one grid's 65535 rows on a scorer that takes the general kernel (partial_ratio, and
+    a distance kind): the launch is sliced, every row is written."""
+    cand = ["coke zero", "sprite", "fanta orange", "coke sleek can", "x"]
+    base = ["coke", "zero coke", "sprite zero", "orange", "q", ""]
+    nq = 66_000
+    queries = [base[i % len(base)] for i in range(nq)]
+    buf, o = fast_oracle.pack(cand)
+    with Corpus.from_prepared(cand) as c:
+        got = c.score_all(queries, _lib.PARTIAL)
+        exp6 = np.stack([fast_oracle.score_all(fast_oracle.PARTIAL, q, buf, o) for q in base]).astype(np.uint8)
+        assert (got == exp6[np.arange(nq) % len(base)]).all()
+        lev = c.distance_all(queries, 1)
+        e6 = np.array([[fast_oracle.levenshtein(q, s) for s in cand] for q in base], dtype=np.uint16)
+        assert (lev == e6[np.arange(nq) % len(base)]).all()

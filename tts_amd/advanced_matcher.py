@@ -29,7 +29,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .corpus import Corpus
+from .corpus import Corpus, LeasedResource, list_fingerprint
 
 SENTINEL = "\x01"            # never produced by normalize_text ([a-z0-9] only)
 
@@ -165,7 +165,7 @@ class CandidateIndex:
 class AdvancedFuzzyMatcher:
     """Advanced Fuzzy Matching Engine with unit conversion support (reference app.py:265-460)."""
 
-    _indexes: "OrderedDict[int, Tuple[Sequence[str], CandidateIndex]]" = OrderedDict()
+    _indexes: "OrderedDict[int, Tuple[tuple, LeasedResource]]" = OrderedDict()
     _max_indexes = 8
     _lock = threading.Lock()
     device = 0
@@ -178,27 +178,38 @@ class AdvancedFuzzyMatcher:
 
     # -- index cache: the reference passes the list on every call (app.py:1847) ---------------------
     @classmethod
-    def index_for(cls, candidates: Sequence[str]) -> CandidateIndex:
+    def _lease_index(cls, candidates: Sequence[str]):
+        """-> (index, lease).  The index of a list is reused while corpus.list_fingerprint says the list is
+        unchanged; an index that was replaced or evicted is closed only once no call is still using it."""
         key = id(candidates)
+        fp = list_fingerprint(candidates)
         with cls._lock:
             ent = cls._indexes.get(key)
-            if ent is not None and ent[0] is candidates and ent[1].n == len(candidates):
+            ix = ent[1].lease() if ent is not None and ent[0] == fp else None
+            if ix is not None:
                 cls._indexes.move_to_end(key)
-                return ent[1]
+                return ix, ent[1]
             if ent is not None:
-                ent[1].close()
-            idx = CandidateIndex(candidates, device=cls.device)
-            cls._indexes[key] = (candidates, idx)
+                ent[1].retire()
+            res = LeasedResource(CandidateIndex(list(candidates), device=cls.device))
+            cls._indexes[key] = (fp, res)
+            cls._indexes.move_to_end(key)
             while len(cls._indexes) > cls._max_indexes:
                 _, (_, old) = cls._indexes.popitem(last=False)
-                old.close()
-            return idx
+                old.retire()
+            return res.lease(), res
+
+    @classmethod
+    def index_for(cls, candidates: Sequence[str]) -> CandidateIndex:
+        ix, lease = cls._lease_index(candidates)
+        lease.release()
+        return ix
 
     @classmethod
     def clear_cache(cls) -> None:
         with cls._lock:
-            for _, idx in cls._indexes.values():
-                idx.close()
+            for _, res in cls._indexes.values():
+                res.retire()
             cls._indexes.clear()
 
     # -- unit conversion shortcut (app.py:348-376), vectorised over the candidates ------------------
@@ -242,17 +253,24 @@ class AdvancedFuzzyMatcher:
             top_n = FUZZY_MATCH_CONFIG['top_n']
         if not query or not candidates:
             return []
-        ix = cls.index_for(candidates)
+        ix, lease = cls._lease_index(candidates)
+        try:
+            return cls._search(query, candidates, ix, threshold, top_n)
+        finally:
+            lease.release()
+
+    @classmethod
+    def _search(cls, query: str, candidates: List[str], ix: CandidateIndex, threshold: float, top_n: int) -> List[Dict]:
         results: List[Tuple[int, Dict]] = []
 
         special = np.zeros(ix.n, dtype=bool)
         for i in ix.lower_index.get(query.lower(), ()):
-            results.append((i, {'value': candidates[i], 'score': 1.0, 'method': 'exact'}))
+            results.append((i, {'value': ix.candidates[i], 'score': 1.0, 'method': 'exact'}))
             special[i] = True
         for i, unit_score in cls._unit_scores(query, ix).items():
             if special[i]:
                 continue
-            results.append((i, {'value': candidates[i],
+            results.append((i, {'value': ix.candidates[i],
                                 'score': unit_score * FUZZY_MATCH_CONFIG['unit_conversion_weight'],
                                 'method': 'unit_conversion'}))
             special[i] = True
@@ -300,7 +318,7 @@ class AdvancedFuzzyMatcher:
                 method_scores = {'prefix': prefix[i], 'substring': substring[i], 'sequence': sequence_score,
                                  'jaccard': max(j2[i], j3[i]), 'levenshtein': lev_score[i]}
                 best_method = max(method_scores, key=method_scores.get)
-                results.append((i, {'value': candidates[i], 'score': float(final_score), 'method': best_method}))
+                results.append((i, {'value': ix.candidates[i], 'score': float(final_score), 'method': best_method}))
 
         results.sort(key=lambda t: t[0])                       # the reference appends in candidate order
         out = [r for _, r in results]

@@ -164,6 +164,55 @@ class Corpus:
         _lib.check(self._lib.fz_set_workspace_limit(self._handle(), int(nbytes)))
 
 
+def list_fingerprint(items: Sequence[str]):
+    """What a drop-in compares to decide whether the list it uploaded is still the list it is handed.
+    The reference re-reads its lists on every call (src/fuzzy_search.py:17-18), so an edit made in place
+    must be seen: lists of up to 4 096 items are hashed in full (Python caches each string's hash, so
+    this costs tens of microseconds), longer ones by identity, length and 256 evenly spaced items --
+    after an in-place edit of a longer list call the owner's ``refresh()``."""
+    n = len(items)
+    if n <= 4096:
+        return (id(items), n, hash(tuple(items)))
+    step = max(1, n // 256)
+    return (id(items), n, hash(tuple(items[i] for i in range(0, n, step))), hash(items[-1]))
+
+
+class LeasedResource:
+    """A device resource (anything with ``close()``) shared by concurrent callers: ``lease()`` hands it
+    out counted, ``retire()`` closes it once the last lease is back.  This is what lets a drop-in
+    replace a corpus whose list changed while another session thread is still inside a query on it
+    (the reference's object is shared by every Streamlit session, utils/helper_components.py:59-64)."""
+
+    def __init__(self, resource):
+        import threading
+        self.resource = resource
+        self._lock = threading.Lock()
+        self._users = 0
+        self._retired = False
+
+    def lease(self):
+        with self._lock:
+            if self._retired:
+                return None
+            self._users += 1
+            return self.resource
+
+    def release(self) -> None:
+        with self._lock:
+            self._users -= 1
+            close_now = self._retired and self._users == 0
+        if close_now:
+            self.resource.close()
+
+    def retire(self) -> None:
+        with self._lock:
+            already = self._retired
+            self._retired = True
+            close_now = not already and self._users == 0
+        if close_now:
+            self.resource.close()
+
+
 def distance_batch(a: Sequence[str], b: Sequence[str], kind: int = 0, device: int = 0) -> np.ndarray:
     """Distances of explicit pairs (a[i], b[i]) through ``fz_distance_batch``: uint32 [n]."""
     if len(a) != len(b):

@@ -15,6 +15,7 @@
 #define FZ_MODE_NHITS 5
 #define FZ_MODE_FIND 6
 #define FZ_IDX_BITS 40
+#define FZ_GRID_Y_MAX 65535u   // rows of one launch that indexes them by blockIdx.y
 #define FZ_IDX_MASK ((1ull << FZ_IDX_BITS) - 1ull)
 
 // One 64-candidate tile.  Symbols: dword d of lane l at sym[coff + d*64 + l] (4 8-bit symbols per

@@ -13,9 +13,13 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
+#include <new>
+#include <stdexcept>
 #include <mutex>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -56,6 +60,24 @@ static int fail(int code, const char *fmt, ...)
             return fail(FZ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
                         __FILE__, __LINE__);                                                   \
     } while (0)
+
+// No C++ exception may cross the C ABI (a std::bad_alloc from a corrupt size field or plain memory
+// exhaustion would abort the host process): every extern "C" body runs inside guarded().
+template <typename F>
+static int guarded(F &&f) noexcept
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(FZ_ERR_LIMIT, "out of host memory");
+    } catch (const std::length_error &e) {
+        return fail(FZ_ERR_LIMIT, "size beyond what the host can allocate: %s", e.what());
+    } catch (const std::exception &e) {
+        return fail(FZ_ERR_INVALID, "unexpected failure: %s", e.what());
+    } catch (...) {
+        return fail(FZ_ERR_INVALID, "unexpected failure");
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // tokens
@@ -487,15 +509,17 @@ static int corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, 
     for (uint64_t i = lo; i < hi; ++i)
         if (cps[i] >= 0x110000u) return fail(FZ_ERR_INVALID, "code point 0x%x out of range at %llu", cps[i], (unsigned long long)i);
 
-    fz_corpus *c = new fz_corpus();
+    struct CorpusDeleter { void operator()(fz_corpus *p) const { fz_corpus_destroy(p); } };
+    std::unique_ptr<fz_corpus, CorpusDeleter> holder(new fz_corpus());     // released on every way out
+    fz_corpus *c = holder.get();
     c->device = device; c->base = base_index; c->n = n;
     c->h_cps.assign(cps + lo, cps + hi);
     c->h_offs.resize(n + 1);
     for (uint64_t i = 0; i <= n; ++i) c->h_offs[i] = n ? offs[i] - lo : 0;
     int rc = build_view(c, eager_view);
     if (rc == FZ_OK) rc = finish_create(c);
-    if (rc != FZ_OK) { fz_corpus_destroy(c); return rc; }
-    *out = c;
+    if (rc != FZ_OK) return rc;
+    *out = holder.release();
     return FZ_OK;
 }
 
@@ -529,7 +553,7 @@ static int finish_create(fz_corpus *c)
     return FZ_OK;
 }
 
-extern "C" int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
+static int fz_corpus_create_impl(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
                                 uint64_t base_index, fz_corpus **out)
 {
     return corpus_create(cps, offs, n, device, base_index, VIEW_SET, out);
@@ -566,7 +590,7 @@ static int load_device(FILE *f, T **d, size_t n, uint64_t *bytes)
     return upload(d, h, bytes);
 }
 
-extern "C" int fz_corpus_save(fz_corpus *c, const char *path)
+static int fz_corpus_save_impl(fz_corpus *c, const char *path)
 {
     if (!c || !path) return fail(FZ_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -612,7 +636,7 @@ extern "C" int fz_corpus_save(fz_corpus *c, const char *path)
 
 static int finish_create(fz_corpus *c);
 
-extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index, fz_corpus **out)
+static int fz_corpus_load_impl(const char *path, int device, uint64_t base_index, fz_corpus **out)
 {
     if (!out || !path) return fail(FZ_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -622,16 +646,32 @@ extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index,
     if (device < 0 || device >= ndev) return fail(FZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
     HIP_TRY(hipSetDevice(device));
     std::call_once(g_ties_once, make_tie_tables);
-    FILE *f = fopen(path, "rb");
+    // the file and the half-built corpus are released on every way out, an exception included
+    struct FileCloser { void operator()(FILE *fp) const { if (fp) fclose(fp); } };
+    struct CorpusDeleter { void operator()(fz_corpus *p) const { fz_corpus_destroy(p); } };
+    std::unique_ptr<FILE, FileCloser> file(fopen(path, "rb"));
+    FILE *f = file.get();
     if (!f) return fail(FZ_ERR_INVALID, "cannot open %s", path);
-    fz_corpus *c = new fz_corpus();
-    auto bad = [&](const char *why) { fclose(f); fz_corpus_destroy(c); return fail(FZ_ERR_INVALID, "%s: %s", path, why); };
+    if (fseek(f, 0, SEEK_END) != 0) return fail(FZ_ERR_INVALID, "%s: cannot seek", path);
+    const long long fsize_ll = ftell(f);
+    if (fsize_ll < 0 || fseek(f, 0, SEEK_SET) != 0) return fail(FZ_ERR_INVALID, "%s: cannot seek", path);
+    const uint64_t fsize = (uint64_t)fsize_ll;
+    // a declared element count is believed only if that many elements can still follow in the file: a
+    // corrupt size field is refused here instead of reaching a vector constructor
+    auto fits = [&](uint64_t count, uint64_t elem_bytes) {
+        const long long pos = ftell(f);
+        return pos >= 0 && count <= (fsize - (uint64_t)pos) / elem_bytes;
+    };
+    std::unique_ptr<fz_corpus, CorpusDeleter> holder(new fz_corpus());
+    fz_corpus *c = holder.get();
+    auto bad = [&](const char *why) { return fail(FZ_ERR_INVALID, "%s: %s", path, why); };
     char magic[8]; uint64_t hdr[3];
     if (!get(f, magic, 8) || memcmp(magic, kFileMagic, 8) != 0) return bad("not a packed corpus file (magic FZCORP01)");
     if (!get(f, hdr, 3)) return bad("truncated header");
     c->device = device; c->n = hdr[0];
     c->base = base_index == ~0ull ? hdr[1] : base_index;      // ~0: keep the base index the file was saved with
     if (c->n >= 0xFFFFFFFFull - 64 || c->base + c->n > FZ_IDX_MASK) return bad("candidate count or base index out of range");
+    if (!fits(hdr[2], 4)) return bad("vocabulary count exceeds the file size");
     for (uint64_t i = 0; i < hdr[2]; ++i) {
         uint32_t len;
         if (!get(f, &len, 1) || len > FZ_MAX_CAND_LEN) return bad("bad vocabulary entry");
@@ -641,8 +681,10 @@ extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index,
         c->vocab.emplace(Tok(c->vocab_store.back()), (uint32_t)i);
     }
     uint64_t ncps;
-    if (!get(f, &ncps, 1) || ncps > (1ull << 40)) return bad("bad input section");
-    c->h_cps.resize(ncps); c->h_offs.resize(c->n + 1);
+    if (!get(f, &ncps, 1) || ncps > (1ull << 40) || !fits(ncps, 4)) return bad("bad input section");
+    c->h_cps.resize(ncps);
+    if (!fits(ncps + 2 * (c->n + 1), 4)) return bad("truncated input section");
+    c->h_offs.resize(c->n + 1);
     if (!get(f, c->h_cps.data(), ncps) || !get(f, c->h_offs.data(), c->n + 1)) return bad("truncated input section");
     for (uint64_t i = 0; i < c->n; ++i)
         if (c->h_offs[i + 1] < c->h_offs[i] || c->h_offs[i + 1] > ncps) return bad("offsets out of range");
@@ -662,6 +704,10 @@ extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index,
             v.alphabet > 0x10000u || v.n_sym_words > 0xFFFFFFFFull || v.n_tok_slots > 0xFFFFFFFFull ||
             vh[14] > 2ull * 0x110000ull || (vh[14] & 1ull))
             return bad("inconsistent view header");
+        // what the header promises must still be in the file: alphabet pairs, symbols, token ids and ends,
+        // tiles, both permutations
+        if (!fits(vh[14] + v.n_sym_words + v.n_tok_slots + (v.n_tok_slots + 1) / 2 + 3ull * v.ntiles + v.npad + c->n, 4))
+            return bad("view arrays exceed the file size");
         std::vector<uint32_t> alpha(vh[14]);
         if (!get(f, alpha.data(), alpha.size())) return bad("truncated alphabet");
         v.sym_of_cp.assign(0x110000, 0);
@@ -719,11 +765,11 @@ extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index,
         if (rc != FZ_OK) break;
         v.built = true;
     }
-    fclose(f);
+    file.reset();
     if (rc == FZ_OK && !c->views[VIEW_SET].built) rc = build_view(c, VIEW_SET);
     if (rc == FZ_OK) rc = finish_create(c);
-    if (rc != FZ_OK) { fz_corpus_destroy(c); return rc; }
-    *out = c;
+    if (rc != FZ_OK) return rc;
+    *out = holder.release();
     return FZ_OK;
 }
 
@@ -758,6 +804,7 @@ extern "C" int fz_set_workspace_limit(fz_corpus *c, uint64_t bytes)
 extern "C" int fz_last_timing(const fz_corpus *c, fz_timing *out)
 {
     if (!c || !out) return fail(FZ_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(const_cast<fz_corpus *>(c)->mu);   // a query call on another thread rewrites it
     *out = c->timing;
     return FZ_OK;
 }
@@ -1257,9 +1304,12 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             sp.min_score = min_score; sp.k = k; sp.base_index = c->base;
             sp.out_keys = d_keys + q0 * k; sp.out_cnt = d_cnt ? d_cnt + q0 : nullptr;
             sp.flat = o.flat;
+            struct DevFree { void operator()(uint64_t *p) const { if (p) (void)hipFree(p); } };
+            std::unique_ptr<uint64_t, DevFree> dbg_holder;       // freed on the early returns below too
             uint64_t *d_dbg = nullptr;
             if (getenv("FUZZYHIP_SELECT_DEBUG")) {
                 HIP_TRY(hipMalloc((void **)&d_dbg, (size_t)rows * 64));
+                dbg_holder.reset(d_dbg);
                 HIP_TRY(hipMemsetAsync(d_dbg, 0, (size_t)rows * 64, st));
                 sp.dbg = d_dbg;
             }
@@ -1268,7 +1318,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
                 std::vector<uint64_t> h((size_t)rows * 8);
                 HIP_TRY(hipStreamSynchronize(st));
                 HIP_TRY(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
-                (void)hipFree(d_dbg);
+                dbg_holder.reset();
                 uint32_t worst = 0;
                 for (uint32_t r = 0; r < rows; ++r) if (h[r * 8 + 4] - h[r * 8] > h[worst * 8 + 4] - h[worst * 8]) worst = r;
                 const uint64_t *w = &h[(size_t)worst * 8];
@@ -1319,7 +1369,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     return FZ_OK;
 }
 
-extern "C" int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+static int fz_query_topk_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                              int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx,
                              int32_t *out_score, uint32_t *out_cnt)
 {
@@ -1331,7 +1381,7 @@ extern "C" int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t
     return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_HOST, o);
 }
 
-extern "C" int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs,
+static int fz_query_topk_keys_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs,
                                   uint32_t nq, int scorer, int32_t min_score, uint32_t k,
                                   uint64_t *out_keys_device, uint32_t *out_cnt_device, int sync)
 {
@@ -1343,7 +1393,7 @@ extern "C" int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uin
     return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_DEVICE, o);
 }
 
-extern "C" int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+static int fz_score_all_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                             int scorer, uint8_t *out_scores)
 {
     if (nq && c && c->n && !out_scores) return fail(FZ_ERR_INVALID, "null output buffer");
@@ -1353,7 +1403,7 @@ extern "C" int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t 
     return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, 0, 0, RUN_SCORE_ALL, o);
 }
 
-extern "C" int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+static int fz_distance_all_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                                int kind, uint16_t *out_dist)
 {
     if (kind < 0 || kind > 3) return fail(FZ_ERR_INVALID, "kind must be 0 (InDel), 1 (Levenshtein), 2 (common tokens) or 3 (substring)");
@@ -1367,7 +1417,7 @@ extern "C" int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64
 // Two scorers over two corpora that hold the SAME candidate list in two string forms (e.g. the
 // normalised strings for partial_ratio and their full_process-ed forms for token_set_ratio),
 // combined per candidate through the caller's 101 x 101 rank table, then top-k on the rank.
-extern "C" int fz_query_topk_pair(fz_corpus *ca, int scorer_a, const uint32_t *qa_cps, const uint64_t *qa_offs,
+static int fz_query_topk_pair_impl(fz_corpus *ca, int scorer_a, const uint32_t *qa_cps, const uint64_t *qa_offs,
                                   fz_corpus *cb, int scorer_b, const uint32_t *qb_cps, const uint64_t *qb_offs,
                                   uint32_t nq, const uint16_t *rank_tab, uint32_t min_rank, uint32_t k,
                                   uint64_t *out_idx, int32_t *out_rank, uint32_t *out_cnt)
@@ -1434,20 +1484,40 @@ extern "C" int fz_query_topk_pair(fz_corpus *ca, int scorer_a, const uint32_t *q
 // Deterministic merge of per-shard key lists: plain descending sort of the n_lists*k keys of each
 // query.  A key orders by (score desc, global index asc), so the result does not depend on how the
 // corpus was sharded or on the order the lists were gathered in.
-extern "C" int fz_merge_topk(const uint64_t *keys, uint32_t n_lists, uint32_t nq, uint32_t k,
+static int fz_merge_topk_impl(const uint64_t *keys, uint32_t n_lists, uint32_t nq, uint32_t k,
                              uint64_t *out_idx, int32_t *out_score, uint32_t *out_cnt)
 {
     if ((uint64_t)n_lists * nq * k && (!keys || !out_idx || !out_score)) return fail(FZ_ERR_INVALID, "null argument");
-    std::vector<uint64_t> tmp, merged((size_t)nq * k, 0ull);
-    for (uint32_t q = 0; q < nq; ++q) {
-        tmp.clear();
-        for (uint32_t l = 0; l < n_lists; ++l)
-            for (uint32_t i = 0; i < k; ++i) {
-                uint64_t key = keys[((uint64_t)l * nq + q) * k + i];
-                if (key) tmp.push_back(key);
-            }
-        std::sort(tmp.begin(), tmp.end(), [](uint64_t a, uint64_t b) { return a > b; });
-        for (uint32_t i = 0; i < k && i < tmp.size(); ++i) merged[(size_t)q * k + i] = tmp[i];
+    std::vector<uint64_t> merged((size_t)nq * k, 0ull);
+    auto merge_range = [&](uint32_t qa, uint32_t qb) {
+        std::vector<uint64_t> tmp;
+        for (uint32_t q = qa; q < qb; ++q) {
+            tmp.clear();
+            for (uint32_t l = 0; l < n_lists; ++l)
+                for (uint32_t i = 0; i < k; ++i) {
+                    uint64_t key = keys[((uint64_t)l * nq + q) * k + i];
+                    if (key) tmp.push_back(key);
+                }
+            const size_t keep = std::min<size_t>(k, tmp.size());          // only the first k are wanted
+            std::partial_sort(tmp.begin(), tmp.begin() + keep, tmp.end(), [](uint64_t a, uint64_t b) { return a > b; });
+            for (size_t i = 0; i < keep; ++i) merged[(size_t)q * k + i] = tmp[i];
+        }
+    };
+    // a C3-sized exchange (10^4 queries x 8 shards x 10 keys) is ~15 ms on one host thread: queries are
+    // independent, so large merges are cut over a few threads
+    const uint64_t work = (uint64_t)n_lists * nq * k;
+    uint32_t nthreads = work < 200000ull ? 1u : (uint32_t)std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("FUZZYHIP_MERGE_THREADS")) nthreads = (uint32_t)std::min(64, std::max(1, atoi(e)));
+    if (nthreads <= 1u) {
+        merge_range(0, nq);
+    } else {
+        std::vector<std::thread> pool;
+        const uint32_t per = (nq + nthreads - 1u) / nthreads;
+        for (uint32_t t = 0; t < nthreads; ++t) {
+            const uint32_t qa = std::min(nq, t * per), qb = std::min(nq, qa + per);
+            if (qa < qb) pool.emplace_back(merge_range, qa, qb);
+        }
+        for (std::thread &t : pool) t.join();
     }
     if (nq && k) decode_keys(merged.data(), nq, k, out_idx, out_score, out_cnt);
     else if (out_cnt) memset(out_cnt, 0, (size_t)nq * 4);
@@ -1457,7 +1527,7 @@ extern "C" int fz_merge_topk(const uint64_t *keys, uint32_t n_lists, uint32_t nq
 // Explicit pairs: group the pairs by their `a` string; each distinct `a` becomes one query against
 // a temporary raw view of its `b` strings, so the distances come out of the very kernels the
 // scorers use (pattern = a, text = b).
-extern "C" int fz_distance_batch(int device, int kind, const uint32_t *a_cps, const uint64_t *a_offs,
+static int fz_distance_batch_impl(int device, int kind, const uint32_t *a_cps, const uint64_t *a_offs,
                                  const uint32_t *b_cps, const uint64_t *b_offs, uint64_t n_pairs,
                                  uint32_t *out_dist)
 {
@@ -1479,14 +1549,85 @@ extern "C" int fz_distance_batch(int device, int kind, const uint32_t *a_cps, co
         fz_corpus *c = nullptr;
         int rc = corpus_create(cps.data(), offs.data(), g.second.size(), device, 0, VIEW_RAW, &c);
         if (rc != FZ_OK) return rc;
+        struct CorpusDeleter { void operator()(fz_corpus *p) const { fz_corpus_destroy(p); } };
+        std::unique_ptr<fz_corpus, CorpusDeleter> holder(c);
         std::vector<uint32_t> q(g.first.begin(), g.first.end());
         if (q.empty()) q.push_back(0);
         uint64_t qo[2] = {0, g.first.size()};
         std::vector<uint16_t> d(g.second.size());
-        rc = fz_distance_all(c, q.data(), qo, 1, kind, d.data());
-        fz_corpus_destroy(c);
+        rc = fz_distance_all_impl(c, q.data(), qo, 1, kind, d.data());
+        holder.reset();
         if (rc != FZ_OK) return rc;
         for (size_t j = 0; j < g.second.size(); ++j) out_dist[g.second[j]] = d[j];
     }
     return FZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the C ABI: every entry point that can allocate runs inside guarded() (no exception leaves the library)
+// ---------------------------------------------------------------------------------------------
+extern "C" int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
+                                uint64_t base_index, fz_corpus **out)
+{
+    return guarded([&] { return fz_corpus_create_impl(cps, offs, n, device, base_index, out); });
+}
+
+extern "C" int fz_corpus_save(fz_corpus *c, const char *path)
+{
+    return guarded([&] { return fz_corpus_save_impl(c, path); });
+}
+
+extern "C" int fz_corpus_load(const char *path, int device, uint64_t base_index, fz_corpus **out)
+{
+    return guarded([&] { return fz_corpus_load_impl(path, device, base_index, out); });
+}
+
+extern "C" int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                             int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx,
+                             int32_t *out_score, uint32_t *out_cnt)
+{
+    return guarded([&] { return fz_query_topk_impl(c, q_cps, q_offs, nq, scorer, min_score, k, out_idx, out_score, out_cnt); });
+}
+
+extern "C" int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs,
+                                  uint32_t nq, int scorer, int32_t min_score, uint32_t k,
+                                  uint64_t *out_keys_device, uint32_t *out_cnt_device, int sync)
+{
+    return guarded([&] { return fz_query_topk_keys_impl(c, q_cps, q_offs, nq, scorer, min_score, k, out_keys_device, out_cnt_device, sync); });
+}
+
+extern "C" int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                            int scorer, uint8_t *out_scores)
+{
+    return guarded([&] { return fz_score_all_impl(c, q_cps, q_offs, nq, scorer, out_scores); });
+}
+
+extern "C" int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                               int kind, uint16_t *out_dist)
+{
+    return guarded([&] { return fz_distance_all_impl(c, q_cps, q_offs, nq, kind, out_dist); });
+}
+
+extern "C" int fz_query_topk_pair(fz_corpus *ca, int scorer_a, const uint32_t *qa_cps, const uint64_t *qa_offs,
+                                  fz_corpus *cb, int scorer_b, const uint32_t *qb_cps, const uint64_t *qb_offs,
+                                  uint32_t nq, const uint16_t *rank_tab, uint32_t min_rank, uint32_t k,
+                                  uint64_t *out_idx, int32_t *out_rank, uint32_t *out_cnt)
+{
+    return guarded([&] {
+        return fz_query_topk_pair_impl(ca, scorer_a, qa_cps, qa_offs, cb, scorer_b, qb_cps, qb_offs, nq, rank_tab,
+                                       min_rank, k, out_idx, out_rank, out_cnt);
+    });
+}
+
+extern "C" int fz_merge_topk(const uint64_t *keys, uint32_t n_lists, uint32_t nq, uint32_t k,
+                             uint64_t *out_idx, int32_t *out_score, uint32_t *out_cnt)
+{
+    return guarded([&] { return fz_merge_topk_impl(keys, n_lists, nq, k, out_idx, out_score, out_cnt); });
+}
+
+extern "C" int fz_distance_batch(int device, int kind, const uint32_t *a_cps, const uint64_t *a_offs,
+                                 const uint32_t *b_cps, const uint64_t *b_offs, uint64_t n_pairs,
+                                 uint32_t *out_dist)
+{
+    return guarded([&] { return fz_distance_batch_impl(device, kind, a_cps, a_offs, b_cps, b_offs, n_pairs, out_dist); });
 }

@@ -1595,21 +1595,31 @@ static hipError_t launch_general(int mode, const FzScoreParams &p, dim3 grid, si
 hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq, hipStream_t st)
 {
     if (nq == 0u || p.ntiles == 0u) return hipSuccess;
-    dim3 grid((p.ntiles + p.tiles_per_block - 1u) / p.tiles_per_block, nq);
-    size_t lds = fz_score_lds_bytes(W, p);
-    switch (W) {
-    case 1: return launch_general<1>(mode, p, grid, lds, st);
-    case 2: return launch_general<2>(mode, p, grid, lds, st);
-    case 3: return launch_general<3>(mode, p, grid, lds, st);
-    case 4: return launch_general<4>(mode, p, grid, lds, st);
-    case 6: return launch_general<6>(mode, p, grid, lds, st);
-    case 8: return launch_general<8>(mode, p, grid, lds, st);
-    case 12: return launch_general<12>(mode, p, grid, lds, st);
-    case 16: return launch_general<16>(mode, p, grid, lds, st);
-    case 24: return launch_general<24>(mode, p, grid, lds, st);
-    case 32: return launch_general<32>(mode, p, grid, lds, st);
-    default: return hipErrorInvalidValue;
+    const size_t lds = fz_score_lds_bytes(W, p);
+    // blockIdx.y indexes the queries of the launch and a grid holds at most 65535 rows in y: a larger
+    // batch goes in slices, each with its own window of the query list
+    for (uint32_t q0 = 0u; q0 < nq; q0 += FZ_GRID_Y_MAX) {
+        const uint32_t cnt = nq - q0 < FZ_GRID_Y_MAX ? nq - q0 : FZ_GRID_Y_MAX;
+        FzScoreParams ps = p;
+        ps.queries = p.queries + q0;
+        const dim3 grid((p.ntiles + p.tiles_per_block - 1u) / p.tiles_per_block, cnt);
+        hipError_t e;
+        switch (W) {
+        case 1: e = launch_general<1>(mode, ps, grid, lds, st); break;
+        case 2: e = launch_general<2>(mode, ps, grid, lds, st); break;
+        case 3: e = launch_general<3>(mode, ps, grid, lds, st); break;
+        case 4: e = launch_general<4>(mode, ps, grid, lds, st); break;
+        case 6: e = launch_general<6>(mode, ps, grid, lds, st); break;
+        case 8: e = launch_general<8>(mode, ps, grid, lds, st); break;
+        case 12: e = launch_general<12>(mode, ps, grid, lds, st); break;
+        case 16: e = launch_general<16>(mode, ps, grid, lds, st); break;
+        case 24: e = launch_general<24>(mode, ps, grid, lds, st); break;
+        case 32: e = launch_general<32>(mode, ps, grid, lds, st); break;
+        default: return hipErrorInvalidValue;
+        }
+        if (e != hipSuccess) return e;
     }
+    return hipSuccess;
 }
 
 hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st)
@@ -1623,8 +1633,17 @@ hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_
 {
     if (rows == 0u || p.n == 0u) return hipSuccess;
     const uint32_t bx = (uint32_t)((p.n + 255u) / 256u);
-    hipLaunchKernelGGL(fz_combine_rank, dim3(bx < 2048u ? bx : 2048u, rows), dim3(256), 0, st, p);
-    return hipGetLastError();
+    for (uint32_t r0 = 0u; r0 < rows; r0 += FZ_GRID_Y_MAX) {          // blockIdx.y = row: at most 65535 per launch
+        const uint32_t cnt = rows - r0 < FZ_GRID_Y_MAX ? rows - r0 : FZ_GRID_Y_MAX;
+        FzCombineParams ps = p;
+        ps.scores_a = p.scores_a + (uint64_t)r0 * p.stride_a;
+        ps.scores_b = p.scores_b + (uint64_t)r0 * p.stride_b;
+        ps.ranks = p.ranks + (uint64_t)r0 * p.stride_r;
+        hipLaunchKernelGGL(fz_combine_rank, dim3(bx < 2048u ? bx : 2048u, cnt), dim3(256), 0, st, ps);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t fz_launch_select16(const FzSelect16Params &p, uint32_t rows, hipStream_t st)

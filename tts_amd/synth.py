@@ -66,6 +66,26 @@ def make_corpus(n: int, max_chars: int = 64, seed: int = CORPUS_SEED, vocab_size
     return cps, offs
 
 
+def make_corpus_blocks(b0: int, b1: int, per_block: int, max_chars: int = 64, seed: int = CORPUS_SEED,
+                       workers: int = 8, **gen) -> Tuple[np.ndarray, np.ndarray]:
+    """Blocks b0..b1-1 of a corpus defined block by block (block b = make_corpus(per_block, seed = seed +
+    1000 + b)), concatenated.  The whole corpus is the same whatever range a rank asks for, which is what
+    lets bench.py shard ONE 10^8-candidate corpus (C3) over any number of ranks without any rank ever
+    generating all of it.  Blocks are generated on a few threads (numpy releases the GIL in its bulk loops)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if b1 <= b0:
+        return np.zeros(0, dtype=np.uint32), np.zeros(1, dtype=np.uint64)
+    with ThreadPoolExecutor(max(1, min(workers, b1 - b0))) as ex:
+        parts = list(ex.map(lambda b: make_corpus(per_block, max_chars=max_chars, seed=seed + 1000 + b, **gen), range(b0, b1)))
+    cps = np.concatenate([p[0] for p in parts])
+    offs = np.zeros((b1 - b0) * per_block + 1, dtype=np.uint64)
+    base = 0
+    for i, (c, o) in enumerate(parts):
+        offs[i * per_block + 1:(i + 1) * per_block + 1] = o[1:] + np.uint64(base)
+        base += int(o[-1])
+    return cps, offs
+
+
 def to_strings(cps: np.ndarray, offs: np.ndarray, lo: int = 0, hi: int = None) -> List[str]:
     hi = len(offs) - 1 if hi is None else hi
     raw = cps.astype(np.uint8).tobytes().decode("ascii") if cps.max(initial=0) < 128 else None

@@ -17,6 +17,7 @@ There is no CPU path: construction raises if the library or a GPU is missing."""
 from __future__ import annotations
 
 import ctypes
+import functools
 import logging
 from typing import Dict, List, Literal, Tuple
 
@@ -37,14 +38,17 @@ def weighted_score(partial_int: int, token_set_int: int) -> float:
     return min(score, 0.99)
 
 
+@functools.lru_cache(maxsize=16)
 def rank_table(threshold: float):
-    """-> (rank_tab uint16 [101*101], values list (rank r has value values[r-1]), min_rank)."""
+    """-> (rank_tab uint16 [101*101], values list (rank r has value values[r-1]), min_rank).
+    About 30 000 Python float evaluations: cached per threshold, not redone per query."""
     vals = sorted({weighted_score(a, b) for a in range(101) for b in range(101)})
     rank_of = {v: i + 1 for i, v in enumerate(vals)}
     tab = np.zeros(101 * 101, dtype=np.uint16)
     for a in range(101):
         for b in range(101):
             tab[a * 101 + b] = rank_of[weighted_score(a, b)]
+    tab.setflags(write=False)                          # shared by every caller of the cache
     passing = [rank_of[v] for v in vals if v >= threshold]
     return tab, vals, (min(passing) if passing else 0x10000)
 
@@ -119,7 +123,11 @@ class WeightedFuzzySearch:
         equal_pos = ent.keys.index(query_normalized) if query_normalized in ent.mapping else -1
         tab, vals, min_rank = rank_table(self.threshold)
         matches: List[Tuple[str, float]] = []
-        kk = min(k + (1 if equal_pos >= 0 else 0), _lib.MAX_K)
+        kk = k + (1 if equal_pos >= 0 else 0)
+        if kk > _lib.MAX_K:
+            # the reference would return every passing candidate; the device top-k holds FZ_MAX_K.  Same
+            # behaviour as FuzzySearch / Corpus.topk: an explicit error, never a silently shorter list.
+            raise _lib.FuzzyHipError(f"top_n={top_n!r} over {n} candidates needs k={kk}, beyond FZ_MAX_K={_lib.MAX_K}")
         if kk > 0:
             qa_cps, qa_offs = pack_prepared([query_normalized])
             qb_cps, qb_offs = pack_prepared([full_process(query_normalized)])
