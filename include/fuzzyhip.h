@@ -58,6 +58,12 @@ typedef enum {
 #define FZ_MAX_PATTERN 1024u      /* query pattern length in code points incl. token separators */
 #define FZ_MAX_CAND_LEN 16000u    /* canonical candidate length in code points */
 
+/* fz_query_topk_noalloc: size of the library's static device scratch array (held by every GPU the library
+ * runs on until the process ends) and of the pinned host staging each corpus sets aside at creation */
+#define FZ_NOALLOC_SCRATCH_BYTES (32u << 20)
+#define FZ_NOALLOC_BLOB_BYTES (1u << 20)    /* query tables of one chunk */
+#define FZ_NOALLOC_KEYS_BYTES (256u << 10)  /* nq * k * 8 bytes of result keys */
+
 typedef struct fz_corpus fz_corpus;
 
 typedef struct {
@@ -143,6 +149,27 @@ int fz_set_workspace_limit(fz_corpus *c, uint64_t bytes);
 int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                   int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx, int32_t *out_score,
                   uint32_t *out_cnt);
+
+/*
+ * fz_query_topk_noalloc -- fz_query_topk for callers that cannot allocate device memory while they run:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
+ * counterpart in the reference (whose loop allocates Python objects per candidate, src/fuzzy_search.py:22-32).
+ * Same arguments, same results bit for bit; it calls no hipMalloc / hipFree / hipHostMalloc / hipEventCreate
+ * and no other allocating HIP routine.  Its device scratch -- work-queue counters, query tables, the score
+ * matrix of a chunk, result keys and counts -- is carved out of ONE static __device__ array of
+ * FZ_NOALLOC_SCRATCH_BYTES (32 MiB) per GPU; pinned host staging, events and the scorer's device view were
+ * set up when the corpus was created (a scorer other than FZ_TOKEN_SET needs one earlier fz_query_topk call
+ * with that scorer, which builds its view).  Limits, each refused with FZ_ERR_LIMIT and a message naming
+ * it: query tables of one chunk <= FZ_NOALLOC_BLOB_BYTES, nq * k * 8 <= FZ_NOALLOC_KEYS_BYTES, nq <= 32768,
+ * one score row (the padded candidate count, bytes) <= the ~30 MiB the other parts leave; a batch whose
+ * score matrix is larger goes through the array in chunks of rows.
+ * Every call on a GPU shares that GPU's array: the library serialises the calls of ONE process per GPU,
+ * calls from different processes on one GPU use different copies (one per process), and nothing read from
+ * the array survives the call.  What must start at zero (the work-queue counters) is cleared by the call.
+ */
+int fz_query_topk_noalloc(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                          int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx, int32_t *out_score,
+                          uint32_t *out_cnt);
 
 /*
  * fz_query_topk_keys -- same work, results as packed sort keys for the multi-GPU exchange

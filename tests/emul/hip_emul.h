@@ -53,6 +53,14 @@ struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 2; return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+enum { hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipErrorInvalidDevice = 101 };
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emul_event(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+#define HIP_SYMBOL(x) (&(x))
+static inline hipError_t hipGetSymbolAddress(void **p, const void *sym) { *p = const_cast<void *>(sym); return hipSuccess; }   // a "__device__" array is host memory here
 
 // ---- kernel language ----------------------------------------------------------------------------
 #define __global__

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "fz_set_workspace_limit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64]),
     "fz_query_topk": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int,
                                      ctypes.c_int32, ctypes.c_uint32, c_u64p, c_i32p, c_u32p]),
+    "fz_query_topk_noalloc": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int,
+                                             ctypes.c_int32, ctypes.c_uint32, c_u64p, c_i32p, c_u32p]),
     "fz_query_topk_keys": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int,
                                           ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int]),

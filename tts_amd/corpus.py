@@ -107,15 +107,17 @@ class Corpus:
         q_cps, q_offs = pack_prepared(list(queries))
         return q_cps, q_offs, int(q_offs.size - 1)
 
-    def topk(self, queries, min_score: int, k: int, scorer: int = _lib.TOKEN_SET):
-        """Prepared queries (list of str, or (cps, offs)) -> (idx[nq,k] u64, score[nq,k] i32, cnt[nq])."""
+    def topk(self, queries, min_score: int, k: int, scorer: int = _lib.TOKEN_SET, noalloc: bool = False):
+        """Prepared queries (list of str, or (cps, offs)) -> (idx[nq,k] u64, score[nq,k] i32, cnt[nq]).
+        ``noalloc=True`` goes through ``fz_query_topk_noalloc``: same results, no device allocation
+        (static scratch array; sizes beyond its limits raise)."""
         q_cps, q_offs, nq = self._pack_queries(queries)
         idx = np.zeros((nq, max(k, 1)), dtype=np.uint64)
         score = np.zeros((nq, max(k, 1)), dtype=np.int32)
         cnt = np.zeros(max(nq, 1), dtype=np.uint32)
-        _lib.check(self._lib.fz_query_topk(self._handle(), _u32(q_cps), _u64(q_offs), nq, int(scorer),
-                                           int(min_score), int(k), _u64(idx),
-                                           score.ctypes.data_as(_lib.c_i32p), _u32(cnt)))
+        fn = self._lib.fz_query_topk_noalloc if noalloc else self._lib.fz_query_topk
+        _lib.check(fn(self._handle(), _u32(q_cps), _u64(q_offs), nq, int(scorer), int(min_score), int(k),
+                      _u64(idx), score.ctypes.data_as(_lib.c_i32p), _u32(cnt)))
         return idx[:, :k], score[:, :k], cnt[:nq]
 
     def topk_keys_device(self, queries, min_score: int, k: int, keys_ptr: int, cnt_ptr: int = 0,

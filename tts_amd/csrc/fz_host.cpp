@@ -36,6 +36,7 @@ hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_
 hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st);
 hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_t st);
 hipError_t fz_launch_select16(const FzSelect16Params &p, uint32_t rows, hipStream_t st);
+hipError_t fz_scratch_acquire(int device, void **ptr, size_t *bytes);
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -148,6 +149,19 @@ struct View {
     std::vector<uint32_t> h_orig_of_phys;
 };
 
+// Device memory a query call works in beyond its inputs and outputs.  The ordinary entry points own
+// one per corpus and grow it with hipMalloc as batches get larger; fz_query_topk_noalloc carves one out
+// of the library's static __device__ scratch array (fz_kernels.hip) and never grows it.
+struct Workspace {
+    uint8_t *d_scores = nullptr; size_t scores_cap = 0;   // u8 / u16 score matrix [rows][row_stride]
+    uint8_t *d_qbuf = nullptr; size_t qbuf_cap = 0;       // query blob: Peq tables, token triples, stream records
+    uint64_t *d_keys = nullptr; size_t keys_cap = 0;      // top-k keys [nq][k]
+    uint32_t *d_cnt = nullptr; size_t cnt_cap = 0;        // result counts [nq]
+    uint32_t *d_counters = nullptr;                       // stream kernel work-queue counters (FZ_COUNTER_SLOTS launches x FZ_STREAM_QUEUES)
+    bool fixed = false;                                   // true: carved from the static scratch, a larger need is an error
+};
+#define FZ_COUNTER_SLOTS 64u
+
 struct fz_corpus {
     int device = 0;
     uint64_t base = 0, n = 0;
@@ -163,13 +177,16 @@ struct fz_corpus {
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool overlap = true;
     uint64_t ws_limit = 4ull << 30;
-    uint8_t *d_scores = nullptr; size_t scores_cap = 0;
-    uint8_t *d_qbuf = nullptr; size_t qbuf_cap = 0;
-    uint64_t *d_keys = nullptr; size_t keys_cap = 0;
-    uint32_t *d_cnt = nullptr; size_t cnt_cap = 0;
+    Workspace own_ws;                                     // grown on demand by the ordinary entry points
+    Workspace *ws = &own_ws;                              // fz_query_topk_noalloc points it at the static scratch for one call
     uint8_t *d_score_tab[2] = {nullptr, nullptr};         // stream kernel: T[L][d] per rounding form
-    uint32_t *d_counters = nullptr;                       // stream kernel work-queue counters (64 launches x FZ_STREAM_QUEUES)
     uint32_t counter_next = 0;
+    // pinned host staging: the query blob of a chunk (two buffers, so the host fills one while the copy
+    // engine still reads the other) and the keys read back at the end of a call
+    uint8_t *h_blob[2] = {nullptr, nullptr}; size_t h_blob_cap[2] = {0, 0};
+    hipEvent_t ev_blob[2] = {nullptr, nullptr};
+    uint32_t blob_next = 0;
+    uint64_t *h_keys = nullptr; size_t h_keys_cap = 0;
     uint32_t n_cus = 256;
     uint16_t *d_ranks = nullptr; size_t ranks_cap = 0;    // fz_query_topk_pair: combined ranks, rank table
     uint16_t *d_rank_tab = nullptr; size_t rank_tab_cap = 0;
@@ -272,9 +289,15 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (View &v : c->views) free_view(v);
-    for (void *p : {(void *)c->d_scores, (void *)c->d_qbuf, (void *)c->d_keys, (void *)c->d_cnt,
-                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1], (void *)c->d_ranks, (void *)c->d_rank_tab, (void *)c->d_counters})
+    Workspace &w = c->own_ws;
+    for (void *p : {(void *)w.d_scores, (void *)w.d_qbuf, (void *)w.d_keys, (void *)w.d_cnt,
+                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1], (void *)c->d_ranks, (void *)c->d_rank_tab, (void *)w.d_counters})
         if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_blob[i]) (void)hipHostFree(c->h_blob[i]);
+        if (c->ev_blob[i]) (void)hipEventDestroy(c->ev_blob[i]);
+    }
+    if (c->h_keys) (void)hipHostFree(c->h_keys);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     for (hipStream_t a : c->aux_stream) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
@@ -488,6 +511,7 @@ static int build_view(fz_corpus *c, int kind)
 }
 
 static int finish_create(fz_corpus *c);
+static hipEvent_t get_event(fz_corpus *c, size_t i);
 
 static int corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
                          uint64_t base_index, int eager_view, fz_corpus **out)
@@ -538,8 +562,22 @@ static int finish_create(fz_corpus *c)
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = (uint32_t)prop.multiProcessorCount;
-        HIP_TRY(hipMalloc((void **)&c->d_counters, 64 * FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(c->d_counters, 0, 64 * FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&c->own_ws.d_counters, FZ_COUNTER_SLOTS * FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(c->own_ws.d_counters, 0, FZ_COUNTER_SLOTS * FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t)));
+    }
+    // Everything a call of fz_query_topk_noalloc will need is set up here, once: pinned staging of a fixed
+    // size, the events its timings use, and this device's address of the static scratch array.
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipHostMalloc((void **)&c->h_blob[i], FZ_NOALLOC_BLOB_BYTES, hipHostMallocDefault));
+        c->h_blob_cap[i] = FZ_NOALLOC_BLOB_BYTES;
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_blob[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipHostMalloc((void **)&c->h_keys, FZ_NOALLOC_KEYS_BYTES, hipHostMallocDefault));
+    c->h_keys_cap = FZ_NOALLOC_KEYS_BYTES;
+    if (!get_event(c, 7)) return fail(FZ_ERR_HIP, "hipEventCreate failed");
+    {
+        void *scratch = nullptr; size_t scratch_bytes = 0;
+        HIP_TRY(fz_scratch_acquire(c->device, &scratch, &scratch_bytes));
     }
     if (const char *e = getenv("FUZZYHIP_STREAM_OVERSUB")) c->stream_oversub = (uint32_t)std::min(16, std::max(1, atoi(e)));
     if (const char *e = getenv("FUZZYHIP_CHUNKS")) c->pipe_chunks = (uint32_t)std::min(64, std::max(1, atoi(e)));
@@ -995,9 +1033,13 @@ static int prepare_query(const fz_corpus *c, int kind, const uint32_t *s, uint64
 }
 
 template <typename T>
-static int ensure(T **p, size_t *cap, size_t need_bytes)
+static int ensure(const Workspace &w, T **p, size_t *cap, size_t need_bytes, const char *what)
 {
     if (need_bytes <= *cap) return FZ_OK;
+    if (w.fixed)
+        return fail(FZ_ERR_LIMIT, "fz_query_topk_noalloc: the %s of this call needs %zu bytes, its share of the static scratch "
+                                  "buffer (%u MiB in all) holds %zu; use fz_query_topk for larger batches", what, need_bytes,
+                    (unsigned)(FZ_NOALLOC_SCRATCH_BYTES >> 20), *cap);
     if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
 #ifdef FZ_EXACT_ALLOC          // sanitizer build (tests/emul): no slack, so every overrun is seen
     size_t sz = need_bytes;
@@ -1005,6 +1047,21 @@ static int ensure(T **p, size_t *cap, size_t need_bytes)
     size_t sz = need_bytes + need_bytes / 4 + 256;
 #endif
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), sz));
+    *cap = sz;
+    return FZ_OK;
+}
+
+// pinned host buffer of at least `need` bytes (never grown for a fixed workspace: no allocation there)
+template <typename T>
+static int ensure_pinned(const Workspace &w, T **p, size_t *cap, size_t need_bytes, const char *what)
+{
+    if (need_bytes <= *cap) return FZ_OK;
+    if (w.fixed)
+        return fail(FZ_ERR_LIMIT, "fz_query_topk_noalloc: the %s of this call needs %zu bytes of pinned staging, %zu are set "
+                                  "aside; use fz_query_topk for larger batches", what, need_bytes, *cap);
+    if (*p) { HIP_TRY(hipHostFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t sz = need_bytes + need_bytes / 2 + 4096;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(p), sz, hipHostMallocDefault));
     *cap = sz;
     return FZ_OK;
 }
@@ -1062,7 +1119,7 @@ static int scorer_plan(int scorer, int *view, int *mode, FzTies *ties)
     }
 }
 
-// Scores `rows` queries (q0 .. q0+rows) of one view into c->d_scores, rows [0, rows): builds the
+// Scores `rows` queries (q0 .. q0+rows) of one view into the workspace score matrix, rows [0, rows): builds the
 // query tables on the host, uploads them, launches the scoring kernels on `st`.  `ev_begin`, when
 // given, is recorded between the upload and the first launch.
 static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const uint32_t *q_cps,
@@ -1106,28 +1163,31 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
     const size_t o_qrec = o_rec + b.recs.size() * sizeof(FzRec);
     const size_t o_rows = align16(o_qrec + b.qrec.size() * 4);
     const size_t total = o_rows + 256;
-    std::vector<uint8_t> blob(total);
-    if (!qlist.empty()) memcpy(blob.data() + o_q, qlist.data(), qlist.size() * sizeof(FzQuery));
-    if (!b.peq.empty()) memcpy(blob.data() + o_peq, b.peq.data(), b.peq.size() * 4);
+    // The blob is assembled in pinned host memory and copied without a stream synchronisation: two
+    // buffers take turns, and one is rewritten only after the copy that last read it has completed (its
+    // event), so the host builds the tables of the next chunk while the GPU works on this one.
+    Workspace &w = *c->ws;
+    const uint32_t bi = c->blob_next++ & 1u;
+    HIP_TRY(hipEventSynchronize(c->ev_blob[bi]));
+    if ((rc = ensure_pinned(w, &c->h_blob[bi], &c->h_blob_cap[bi], total, "query tables")) != FZ_OK) return rc;
+    uint8_t *blob = c->h_blob[bi];
+    if (!qlist.empty()) memcpy(blob + o_q, qlist.data(), qlist.size() * sizeof(FzQuery));
+    if (!b.peq.empty()) memcpy(blob + o_peq, b.peq.data(), b.peq.size() * 4);
     if (!b.tok_id.empty()) {
-        memcpy(blob.data() + o_id, b.tok_id.data(), b.tok_id.size() * 4);
-        memcpy(blob.data() + o_pos, b.tok_pos.data(), b.tok_pos.size() * 4);
-        memcpy(blob.data() + o_len, b.tok_len1.data(), b.tok_len1.size() * 4);
+        memcpy(blob + o_id, b.tok_id.data(), b.tok_id.size() * 4);
+        memcpy(blob + o_pos, b.tok_pos.data(), b.tok_pos.size() * 4);
+        memcpy(blob + o_len, b.tok_len1.data(), b.tok_len1.size() * 4);
     }
-    memcpy(blob.data() + o_rec, b.recs.data(), b.recs.size() * sizeof(FzRec));
-    if (!b.qrec.empty()) memcpy(blob.data() + o_qrec, b.qrec.data(), b.qrec.size() * 4);
-    memcpy(blob.data() + o_rows, b.row_of_sym, 256);
+    memcpy(blob + o_rec, b.recs.data(), b.recs.size() * sizeof(FzRec));
+    if (!b.qrec.empty()) memcpy(blob + o_qrec, b.qrec.data(), b.qrec.size() * 4);
+    memcpy(blob + o_rows, b.row_of_sym, 256);
     c->timing.host_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if ((rc = ensure(&c->d_qbuf, &c->qbuf_cap, blob.size())) != FZ_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_qbuf, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));          // blob is pageable host memory owned by this scope
-    if (getenv("FUZZYHIP_PREP_DEBUG")) {
-        const auto t_up = std::chrono::steady_clock::now();
-        fprintf(stderr, "[prep dbg] %u queries: tables %.3f ms, blob %.3f ms (%zu bytes), upload+sync %.3f ms\n", rows,
-                std::chrono::duration<double, std::milli>(t_prep - t0).count(),
-                c->timing.host_prep_ms - std::chrono::duration<double, std::milli>(t_prep - t0).count(),
-                blob.size(), std::chrono::duration<double, std::milli>(t_up - t0).count() - c->timing.host_prep_ms);
-    }
+    if ((rc = ensure(w, &w.d_qbuf, &w.qbuf_cap, total, "query tables")) != FZ_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(w.d_qbuf, blob, total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(c->ev_blob[bi], st));
+    if (getenv("FUZZYHIP_PREP_DEBUG"))
+        fprintf(stderr, "[prep dbg] %u queries: tables %.3f ms, tables + blob %.3f ms (%zu bytes)\n", rows,
+                std::chrono::duration<double, std::milli>(t_prep - t0).count(), c->timing.host_prep_ms, total);
 
     if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, st));
     for (auto &l : launches) {
@@ -1156,12 +1216,12 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
         uint32_t tpb = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(p.nwaves, work / 8192));
         tpb = (tpb + p.nwaves - 1) / p.nwaves * p.nwaves;
         p.tiles_per_block = tpb;
-        p.queries = reinterpret_cast<const FzQuery *>(c->d_qbuf + o_q) + first;
-        p.qblob = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_peq);
-        p.qtok_id = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_id);
-        p.qtok_pos = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_pos);
-        p.qtok_len1 = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_len);
-        p.scores = c->d_scores; p.row_stride = row_stride;
+        p.queries = reinterpret_cast<const FzQuery *>(w.d_qbuf + o_q) + first;
+        p.qblob = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_peq);
+        p.qtok_id = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_id);
+        p.qtok_pos = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_pos);
+        p.qtok_len1 = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_len);
+        p.scores = w.d_scores; p.row_stride = row_stride;
         p.ties = ties;
         HIP_TRY(fz_launch_score(W, kmode, p, count, st));
         c->timing.score_launches++;
@@ -1210,13 +1270,13 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
             // the chip's waves cannot all get a share
             const uint64_t waves_total = (uint64_t)p.grid_blocks * p.nwaves;
             p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1u, 32u / p.q_per_block), p.nitems / waves_total));
-            p.work_counter = c->d_counters + (size_t)(c->counter_next++ & 63u) * FZ_STREAM_QUEUES * FZ_STREAM_QPAD;
+            p.work_counter = w.d_counters + (size_t)(c->counter_next++ % FZ_COUNTER_SLOTS) * FZ_STREAM_QUEUES * FZ_STREAM_QPAD;
             HIP_TRY(hipMemsetAsync(p.work_counter, 0, FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), lst));
-            p.row_of_sym = c->d_qbuf + o_rows;
-            p.recs = reinterpret_cast<const FzRec *>(c->d_qbuf + o_rec);
-            p.qrec = reinterpret_cast<const uint32_t *>(c->d_qbuf + o_qrec);
+            p.row_of_sym = w.d_qbuf + o_rows;
+            p.recs = reinterpret_cast<const FzRec *>(w.d_qbuf + o_rec);
+            p.qrec = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_qrec);
             p.score_tab = c->d_score_tab[kmode == FZ_MODE_TOKEN_SET ? 0 : 1];
-            p.scores = c->d_scores; p.row_stride = (uint32_t)row_stride;
+            p.scores = w.d_scores; p.row_stride = (uint32_t)row_stride;
             if (cls == 0) HIP_TRY(fz_launch_stream_pk(kmode, p, lst));
             else HIP_TRY(fz_launch_stream(W, kmode, p, lst));
             c->timing.score_launches++;
@@ -1233,7 +1293,7 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
 
 static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                        int view_kind, int kmode, FzTies ties, int32_t min_score, uint32_t k,
-                       RunMode mode, RunOut &o)
+                       RunMode mode, RunOut &o, Workspace *fixed_ws = nullptr)
 {
     if (!c) return fail(FZ_ERR_INVALID, "null corpus");
     if (nq && (!q_offs || (!q_cps && q_offs[nq] != q_offs[0]))) return fail(FZ_ERR_INVALID, "null query buffers");
@@ -1242,9 +1302,18 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     int rc;
+    if (fixed_ws && !c->views[view_kind].built)
+        return fail(FZ_ERR_INVALID, "fz_query_topk_noalloc: the device view of this scorer is not built yet (building it allocates); "
+                                    "one fz_query_topk call with the scorer builds it");
     if ((rc = build_view(c, view_kind)) != FZ_OK) return rc;
     const View &v = c->views[view_kind];
     hipStream_t st = c->stream;
+    struct WsSwitch {                                    // the corpus works in `fixed_ws` for this call only
+        fz_corpus *c; Workspace *prev;
+        WsSwitch(fz_corpus *c_, Workspace *f) : c(c_), prev(c_->ws) { if (f) c->ws = f; }
+        ~WsSwitch() { c->ws = prev; }
+    } ws_switch(c, fixed_ws);
+    Workspace &w = *c->ws;
     c->timing = fz_timing{};
 
     const bool nothing = topk && (k == 0 || c->n == 0 || min_score > 100);
@@ -1252,9 +1321,9 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     if (topk && nq && k) {
         if (mode == RUN_TOPK_DEVICE) { d_keys = o.d_keys; d_cnt = o.d_cnt; }
         else {
-            if ((rc = ensure(&c->d_keys, &c->keys_cap, (size_t)nq * k * 8)) != FZ_OK) return rc;
-            if ((rc = ensure(&c->d_cnt, &c->cnt_cap, (size_t)nq * 4)) != FZ_OK) return rc;
-            d_keys = c->d_keys; d_cnt = c->d_cnt;
+            if ((rc = ensure(w, &w.d_keys, &w.keys_cap, (size_t)nq * k * 8, "top-k keys")) != FZ_OK) return rc;
+            if ((rc = ensure(w, &w.d_cnt, &w.cnt_cap, (size_t)nq * 4, "result counts")) != FZ_OK) return rc;
+            d_keys = w.d_keys; d_cnt = w.d_cnt;
         }
     }
     if (nq == 0) return FZ_OK;
@@ -1279,7 +1348,10 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     // query tables of piece i+1 while the GPU scores piece i.
     if (topk && c->pipe_chunks > 1 && nq >= 256u * c->pipe_chunks)
         rows_per_chunk = std::min<uint64_t>(rows_per_chunk, (nq + c->pipe_chunks - 1) / c->pipe_chunks);
-    if ((rc = ensure(&c->d_scores, &c->scores_cap, (size_t)(rows_per_chunk * row_stride * esz))) != FZ_OK) return rc;
+    // a fixed workspace is never grown: the batch goes in as many chunks as its score rows need
+    if (w.fixed) rows_per_chunk = std::min<uint64_t>(rows_per_chunk, w.scores_cap / (row_stride * esz));
+    if (rows_per_chunk == 0) rows_per_chunk = 1;                    // ensure() below reports the shortfall
+    if ((rc = ensure(w, &w.d_scores, &w.scores_cap, (size_t)(rows_per_chunk * row_stride * esz), "score matrix")) != FZ_OK) return rc;
 
     std::vector<Tok> toks;
     std::vector<uint8_t> h_rows;
@@ -1290,8 +1362,12 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
 
     for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk) {
         const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, nq - q0);
+        // a fixed workspace creates nothing, events included: chunks beyond the first reuse the three
+        // events of their predecessor (only the last chunk's kernel times are then reported)
+        if (w.fixed && ev + 3 > c->events.size() - 1) ev = 1;
         hipEvent_t e0 = get_event(c, ev++), e1 = get_event(c, ev++);
         if (!e0 || !e1) return fail(FZ_ERR_HIP, "hipEventCreate failed");
+        if (w.fixed) { score_spans.clear(); select_spans.clear(); }
         if ((rc = score_rows(c, view_kind, kmode, ties, q_cps, q_offs, q0, rows, row_stride, st, e0)) != FZ_OK) return rc;
         HIP_TRY(hipEventRecord(e1, st));
         score_spans.push_back({ev - 2, ev - 1});
@@ -1299,7 +1375,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
 
         if (topk) {
             FzSelectParams sp{};
-            sp.scores = c->d_scores; sp.row_stride = row_stride; sp.n = (uint32_t)c->n;
+            sp.scores = w.d_scores; sp.row_stride = row_stride; sp.n = (uint32_t)c->n;
             sp.orig_of_phys = v.d_orig_of_phys; sp.phys_of_orig = v.d_phys_of_orig;
             sp.min_score = min_score; sp.k = k; sp.base_index = c->base;
             sp.out_keys = d_keys + q0 * k; sp.out_cnt = d_cnt ? d_cnt + q0 : nullptr;
@@ -1334,7 +1410,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
             ev_last = e2;
         } else {
             h_rows.resize((size_t)rows * row_stride * esz);
-            HIP_TRY(hipMemcpyAsync(h_rows.data(), c->d_scores, h_rows.size(), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_rows.data(), w.d_scores, h_rows.size(), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             for (uint32_t r = 0; r < rows; ++r) {
                 if (esz == 1) {
@@ -1352,13 +1428,14 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     }
 
     if (mode == RUN_TOPK_HOST) {
-        std::vector<uint64_t> h_keys((size_t)nq * k);
-        HIP_TRY(hipMemcpyAsync(h_keys.data(), d_keys, h_keys.size() * 8, hipMemcpyDeviceToHost, st));
+        if ((rc = ensure_pinned(w, &c->h_keys, &c->h_keys_cap, (size_t)nq * k * 8, "top-k keys")) != FZ_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_keys, d_keys, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
         hipEvent_t e3 = get_event(c, ev++);
+        if (!e3) return fail(FZ_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(e3, st));
         ev_last = e3;
         HIP_TRY(hipStreamSynchronize(st));
-        decode_keys(h_keys.data(), nq, k, o.idx, o.score, o.cnt);
+        decode_keys(c->h_keys, nq, k, o.idx, o.score, o.cnt);
     } else if (mode == RUN_TOPK_DEVICE) {
         if (!o.sync) return FZ_OK;                  // timings are not collected on the async path
         HIP_TRY(hipStreamSynchronize(st));
@@ -1379,6 +1456,38 @@ static int fz_query_topk_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_
     RunOut o; o.idx = out_idx; o.score = out_score; o.cnt = out_cnt;
     o.flat = (scorer & FZ_ORDER_BY_INDEX) ? 1u : 0u;
     return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_HOST, o);
+}
+
+// fz_query_topk over the static scratch array: nothing is allocated (see include/fuzzyhip.h).
+static std::mutex g_scratch_mu[64];
+
+static int fz_query_topk_noalloc_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                                      int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx,
+                                      int32_t *out_score, uint32_t *out_cnt)
+{
+    if (!c) return fail(FZ_ERR_INVALID, "null corpus");
+    if (nq && k && (!out_idx || !out_score)) return fail(FZ_ERR_INVALID, "null output buffers");
+    int view, kmode; FzTies ties; int rc;
+    if ((rc = scorer_plan(scorer & 0xFF, &view, &kmode, &ties)) != FZ_OK) return rc;
+    if (nq > 32768u) return fail(FZ_ERR_LIMIT, "fz_query_topk_noalloc: nq=%u exceeds 32768 queries per call", nq);
+    if (c->device < 0 || c->device >= 64) return fail(FZ_ERR_INVALID, "device %d out of range", c->device);
+    // every call on this GPU works in the same array: one at a time
+    std::lock_guard<std::mutex> dl(g_scratch_mu[c->device]);
+    void *base = nullptr; size_t bytes = 0;
+    HIP_TRY(fz_scratch_acquire(c->device, &base, &bytes));       // cached since the corpus was created
+    // carve-up (every part a multiple of 256 bytes): counters | keys | counts | query tables | score rows
+    uint8_t *p = static_cast<uint8_t *>(base);
+    Workspace w;
+    w.fixed = true;
+    w.d_counters = reinterpret_cast<uint32_t *>(p);
+    p += (size_t)FZ_COUNTER_SLOTS * FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t);
+    w.d_keys = reinterpret_cast<uint64_t *>(p); w.keys_cap = FZ_NOALLOC_KEYS_BYTES; p += FZ_NOALLOC_KEYS_BYTES;
+    w.d_cnt = reinterpret_cast<uint32_t *>(p); w.cnt_cap = 32768u * 4u; p += 32768u * 4u;
+    w.d_qbuf = p; w.qbuf_cap = FZ_NOALLOC_BLOB_BYTES; p += FZ_NOALLOC_BLOB_BYTES;
+    w.d_scores = p; w.scores_cap = bytes - (size_t)(p - static_cast<uint8_t *>(base));
+    RunOut o; o.idx = out_idx; o.score = out_score; o.cnt = out_cnt;
+    o.flat = (scorer & FZ_ORDER_BY_INDEX) ? 1u : 0u;
+    return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_HOST, o, &w);
 }
 
 static int fz_query_topk_keys_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs,
@@ -1449,12 +1558,13 @@ static int fz_query_topk_pair_impl(fz_corpus *ca, int scorer_a, const uint32_t *
     const uint64_t n = ca->n, stride_r = (n + 7) & ~7ull;
     uint64_t rows_per_chunk = std::max<uint64_t>(1, ca->ws_limit / (std::max<uint64_t>(A.npad, B.npad) + 2 * stride_r));
     rows_per_chunk = std::min<uint64_t>(rows_per_chunk, nq);
-    if ((rc = ensure(&ca->d_scores, &ca->scores_cap, (size_t)(rows_per_chunk * A.npad))) != FZ_OK) return rc;
-    if ((rc = ensure(&cb->d_scores, &cb->scores_cap, (size_t)(rows_per_chunk * B.npad))) != FZ_OK) return rc;
-    if ((rc = ensure(&ca->d_ranks, &ca->ranks_cap, (size_t)(rows_per_chunk * stride_r * 2))) != FZ_OK) return rc;
-    if ((rc = ensure(&ca->d_rank_tab, &ca->rank_tab_cap, (size_t)FZ_RANK_DIM * FZ_RANK_DIM * 2)) != FZ_OK) return rc;
-    if ((rc = ensure(&ca->d_keys, &ca->keys_cap, (size_t)nq * k * 8)) != FZ_OK) return rc;
-    if ((rc = ensure(&ca->d_cnt, &ca->cnt_cap, (size_t)nq * 4)) != FZ_OK) return rc;
+    Workspace &wa = ca->own_ws, &wb = cb->own_ws;
+    if ((rc = ensure(wa, &wa.d_scores, &wa.scores_cap, (size_t)(rows_per_chunk * A.npad), "score matrix")) != FZ_OK) return rc;
+    if ((rc = ensure(wb, &wb.d_scores, &wb.scores_cap, (size_t)(rows_per_chunk * B.npad), "score matrix")) != FZ_OK) return rc;
+    if ((rc = ensure(wa, &ca->d_ranks, &ca->ranks_cap, (size_t)(rows_per_chunk * stride_r * 2), "rank matrix")) != FZ_OK) return rc;
+    if ((rc = ensure(wa, &ca->d_rank_tab, &ca->rank_tab_cap, (size_t)FZ_RANK_DIM * FZ_RANK_DIM * 2, "rank table")) != FZ_OK) return rc;
+    if ((rc = ensure(wa, &wa.d_keys, &wa.keys_cap, (size_t)nq * k * 8, "top-k keys")) != FZ_OK) return rc;
+    if ((rc = ensure(wa, &wa.d_cnt, &wa.cnt_cap, (size_t)nq * 4, "result counts")) != FZ_OK) return rc;
     HIP_TRY(hipMemcpyAsync(ca->d_rank_tab, rank_tab, (size_t)FZ_RANK_DIM * FZ_RANK_DIM * 2, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));                       // rank_tab is the caller's pageable memory
     ca->timing = fz_timing{};
@@ -1464,18 +1574,18 @@ static int fz_query_topk_pair_impl(fz_corpus *ca, int scorer_a, const uint32_t *
         if ((rc = score_rows(ca, va, ma, ta, qa_cps, qa_offs, q0, rows, A.npad, st, nullptr)) != FZ_OK) return rc;
         if ((rc = score_rows(cb, vb, mb, tb, qb_cps, qb_offs, q0, rows, B.npad, st, nullptr)) != FZ_OK) return rc;
         FzCombineParams cp{};
-        cp.scores_a = ca->d_scores; cp.scores_b = cb->d_scores; cp.stride_a = A.npad; cp.stride_b = B.npad;
+        cp.scores_a = wa.d_scores; cp.scores_b = wb.d_scores; cp.stride_a = A.npad; cp.stride_b = B.npad;
         cp.phys_a = A.d_phys_of_orig; cp.phys_b = B.d_phys_of_orig; cp.rank_tab = ca->d_rank_tab;
         cp.ranks = ca->d_ranks; cp.stride_r = stride_r; cp.n = (uint32_t)n;
         HIP_TRY(fz_launch_combine(cp, rows, st));
         FzSelect16Params sp{};
         sp.ranks = ca->d_ranks; sp.stride_r = stride_r; sp.n = (uint32_t)n; sp.min_rank = min_rank; sp.k = k;
-        sp.base_index = ca->base; sp.out_keys = ca->d_keys + q0 * k; sp.out_cnt = ca->d_cnt + q0;
+        sp.base_index = ca->base; sp.out_keys = wa.d_keys + q0 * k; sp.out_cnt = wa.d_cnt + q0;
         HIP_TRY(fz_launch_select16(sp, rows, st));
         ca->timing.pairs += 2ull * rows * n;
     }
     std::vector<uint64_t> h_keys((size_t)nq * k);
-    HIP_TRY(hipMemcpyAsync(h_keys.data(), ca->d_keys, h_keys.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_keys.data(), wa.d_keys, h_keys.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     decode_keys(h_keys.data(), nq, k, out_idx, out_rank, out_cnt);
     return FZ_OK;
@@ -1587,6 +1697,13 @@ extern "C" int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t
                              int32_t *out_score, uint32_t *out_cnt)
 {
     return guarded([&] { return fz_query_topk_impl(c, q_cps, q_offs, nq, scorer, min_score, k, out_idx, out_score, out_cnt); });
+}
+
+extern "C" int fz_query_topk_noalloc(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                                     int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx,
+                                     int32_t *out_score, uint32_t *out_cnt)
+{
+    return guarded([&] { return fz_query_topk_noalloc_impl(c, q_cps, q_offs, nq, scorer, min_score, k, out_idx, out_score, out_cnt); });
 }
 
 extern "C" int fz_query_topk_keys(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs,

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "fuzzyhip.h"
 #include "fz_common.h"
 
@@ -1519,6 +1521,38 @@ __global__ __launch_bounds__(256) void fz_select16_topk(FzSelect16Params p)
         p.out_keys[(uint64_t)blockIdx.x * k + i] = out;
     }
     if (p.out_cnt != nullptr && tid == 0u) p.out_cnt[blockIdx.x] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// static scratch of fz_query_topk_noalloc
+// ---------------------------------------------------------------------------------------------
+// One array per GPU, part of the code object: no call ever allocates it.  In host code the NAME of a
+// __device__ array is not a device address: the address on a given GPU comes from hipGetSymbolAddress
+// with that GPU current, once per device, and only that pointer is handed to kernels, memsets and copies.
+static __device__ __align__(256) unsigned char fz_scratch[FZ_NOALLOC_SCRATCH_BYTES];
+
+#define FZ_MAX_DEVICES 64
+hipError_t fz_scratch_acquire(int device, void **ptr, size_t *bytes)
+{
+    static std::mutex mu;
+    static void *ptrs[FZ_MAX_DEVICES] = {};
+    if (device < 0 || device >= FZ_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(mu);
+    if (ptrs[device] == nullptr) {
+        int cur = -1;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return e;
+        if (cur != device && (e = hipSetDevice(device)) != hipSuccess) return e;
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(fz_scratch));
+        if (cur != device) (void)hipSetDevice(cur);
+        if (e != hipSuccess) return e;
+        if (p == nullptr) return hipErrorInvalidValue;
+        ptrs[device] = p;
+    }
+    *ptr = ptrs[device];
+    *bytes = FZ_NOALLOC_SCRATCH_BYTES;
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------
