@@ -227,6 +227,7 @@ def test_workspace_chunking_and_caller_stream(oracle):
     """A tiny workspace limit forces many query chunks; a caller-provided stream carries the work:
     results must not change."""
     import torch
+    st = torch.cuda.Stream()                     # torch's own HIP initialisation, before the library's work
     cps, offs = synth.make_corpus(20_000, max_chars=64, seed=101)
     queries = synth.make_queries(cps, offs, 37, seed=102)
     with Corpus(cps, offs) as c:
@@ -237,7 +238,6 @@ def test_workspace_chunking_and_caller_stream(oracle):
         for a, b in zip(got, ref):
             assert (a == b).all()
         assert (c.score_all(queries[:5]) == ref_all).all()
-        st = torch.cuda.Stream()
         c.set_stream(st.cuda_stream)
         got = c.topk(queries, 35, 10)
         for a, b in zip(got, ref):

@@ -16,7 +16,7 @@
 
 #define REP8(x) x x x x x x x x
 
-enum { K_ADD, K_BITOP3, K_ADD3, K_SDWA, K_STEP1, K_STEP2, K_STEP_PK, K_STEP_PK_BR, K_SALU, K_LOOP_LDS, N_KINDS };
+enum { K_ADD, K_BITOP3, K_ADD3, K_SDWA, K_STEP1, K_STEP2, K_STEP_PK, K_STEP_PK_BR, K_SALU, K_LOOP_LDS, K_ADD3_V, K_ADD_S, K_STEP_PK_V, K_CMP_OR, K_CNDMASK, K_BFE_I, N_KINDS };
 static const char *kNames[N_KINDS] = {
     "v_add_u32 (4 independent chains)",
     "v_bitop3_b32 (4 independent chains)",
@@ -28,8 +28,14 @@ static const char *kNames[N_KINDS] = {
     "packed-kernel step + s_cmp + s_cbranch (not taken) after every step, as the round-1 loop (VALU counted only)",
     "s_add_u32 / s_and_b32 / s_lshl_b32 / s_cmp (4 SALU per group; counted as instructions)",
     "stream inner loop: 8 x (sdwa address + ds_read_b32), wait, 8 dependent packed steps",
+    "v_add3_u32, all three sources VGPRs (4 independent chains)",
+    "v_add_u32 with an SGPR as src0 (4 independent chains)",
+    "packed-kernel step with the stopper in a VGPR: bitop3 -> add3(vgpr) -> bitop3, one chain",
+    "2 x v_cmp_eq_u32 (SGPR-pair results) + s_or_b64 (3 instructions per group)",
+    "v_cndmask_b32 with an SGPR-pair mask (4 independent chains)",
+    "v_bfe_i32 v, v, 0, 1 + v_lshrrev_b32 (2 per group, dependent)",
 };
-static const int kOpsPerIter[N_KINDS] = {32, 32, 32, 32, 24, 48, 24, 24, 32, 8 * (8 + 8 * 3)};
+static const int kOpsPerIter[N_KINDS] = {32, 32, 32, 32, 24, 48, 24, 24, 32, 8 * (8 + 8 * 3), 32, 32, 24, 24, 32, 16};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *clk, int iters, unsigned sval)
@@ -76,6 +82,26 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *clk,
             REP8(asm volatile("s_add_u32 %0, %0, %2\n s_and_b32 %1, %1, %0\n s_lshl_b32 %1, %1, 1\n s_cmp_eq_u32 %0, %1\n"
                          : "+s"(s0), "+s"(s1) : "s"(sval) : "scc");)
             a += s0 + s1;
+        } else if (KIND == K_ADD3_V) {
+            REP8(asm volatile("v_add3_u32 %0, %0, %4, %5\n v_add3_u32 %1, %1, %4, %5\n v_add3_u32 %2, %2, %4, %5\n v_add3_u32 %3, %3, %4, %5\n"
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f));)
+        } else if (KIND == K_ADD_S) {
+            REP8(asm volatile("v_add_u32 %0, %4, %0\n v_add_u32 %1, %4, %1\n v_add_u32 %2, %4, %2\n v_add_u32 %3, %4, %3\n"
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(sval));)
+        } else if (KIND == K_STEP_PK_V) {
+            REP8(asm volatile("v_bitop3_b32 %1, %0, %2, %3 bitop3:0x80\n v_add3_u32 %4, %0, %1, %5\n v_bitop3_b32 %0, %4, %0, %1 bitop3:0xf6\n"
+                         : "+v"(a), "+v"(c) : "v"(e), "v"(f), "v"(g), "v"(h));)
+        } else if (KIND == K_CMP_OR) {
+            unsigned long long m0_, m1_;
+            REP8(asm volatile("v_cmp_eq_u32 %0, %3, %2\n v_cmp_eq_u32 %1, %4, %2\n s_or_b64 %0, %0, %1\n"
+                         : "=&s"(m0_), "=&s"(m1_) : "v"(a), "s"(sval), "s"(sval + 1u) : "scc");)
+            a += (unsigned)m0_;
+        } else if (KIND == K_CNDMASK) {
+            unsigned long long mk = 0x5555555555555555ull ^ sval;
+            REP8(asm volatile("v_cndmask_b32 %0, %0, %4, %5\n v_cndmask_b32 %1, %1, %4, %5\n v_cndmask_b32 %2, %2, %4, %5\n v_cndmask_b32 %3, %3, %4, %5\n"
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "s"(mk));)
+        } else if (KIND == K_BFE_I) {
+            REP8(asm volatile("v_bfe_i32 %1, %0, 0, 1\n v_lshrrev_b32 %0, 1, %0\n" : "+v"(a), "+v"(b));)
         } else {
             // one "record" of the stream kernels: eight row addresses (column + symbol byte), eight LDS reads,
             // one wait, eight dependent Hyyro steps on the rows read
@@ -151,7 +177,7 @@ int main()
     printf("{\"device\": \"%s\", \"cus\": %d, \"simds\": %d, \"unit\": \"wave64 VALU instructions\", \"results\": [\n", prop.gcnArchName, n_cus, n_cus * 4);
     bool first = true;
     for (int w : {1, 2, 4, 8}) {
-        Result (*fns[N_KINDS])(int, int) = {run<K_ADD>, run<K_BITOP3>, run<K_ADD3>, run<K_SDWA>, run<K_STEP1>, run<K_STEP2>, run<K_STEP_PK>, run<K_STEP_PK_BR>, run<K_SALU>, run<K_LOOP_LDS>};
+        Result (*fns[N_KINDS])(int, int) = {run<K_ADD>, run<K_BITOP3>, run<K_ADD3>, run<K_SDWA>, run<K_STEP1>, run<K_STEP2>, run<K_STEP_PK>, run<K_STEP_PK_BR>, run<K_SALU>, run<K_LOOP_LDS>, run<K_ADD3_V>, run<K_ADD_S>, run<K_STEP_PK_V>, run<K_CMP_OR>, run<K_CNDMASK>, run<K_BFE_I>};
         for (int kind = 0; kind < N_KINDS; ++kind) {
             const Result r = fns[kind](w, n_cus);
             printf("%s  {\"kind\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"clock_ghz\": %.3f, \"cycles_per_instr_per_simd\": %.3f, \"chip_ginstr_per_s\": %.1f}",

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfuzzyhip.so")
+# FUZZYHIP_LIB: another build of the same library (kernel experiments, A/B runs on one box)
+LIB_PATH = os.environ.get("FUZZYHIP_LIB") or os.path.join(_HERE, "libfuzzyhip.so")
 
 TOKEN_SET, RATIO, TOKEN_SORT, PARTIAL, LEVENSHTEIN = 0, 1, 2, 3, 4
 SCORERS = {"token_set": TOKEN_SET, "ratio": RATIO, "token_sort": TOKEN_SORT, "partial": PARTIAL,

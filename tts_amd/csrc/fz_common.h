@@ -71,19 +71,22 @@ struct FzScoreParams {
 
 // ---- stream kernel (fz_score_stream): short candidates as per-lane patterns, queries as text -----
 // Eligible tiles: <= 8 token slots and <= 32*W symbols (W = 1, 2).  Eligible queries: see
-// fz_host.cpp build_stream.  The query side is a stream of 16-byte records, the same for every lane:
-//   header  {out_row, m, n_ids, n_tok_recs}
-//   ids     ceil(n_ids / 4) records of 4 vocabulary ids (pad FZ_QTOK_PAD): the query tokens that
-//           exist in the corpus vocabulary, the only ones that can intersect
-//   tokens  n_tok_recs records {id, nsym | last << 8, 4 symbols, 4 symbols}: up to 8 text symbols
-//           of one token, each byte = 4 * (Peq row of the symbol); a longer token continues in the
-//           next record (id = FZ_QTOK_CONT); `last` marks the record that ends the token, after
-//           which the separator step follows (token_set only).  Symbols no candidate uses are
-//           dropped on the host: they cannot change the LCS state.
+// fz_host.cpp stream_append.  The query side is a stream of 16-byte records, the same for every lane:
+//   header  {out_row, m | n_ids << 8 | n_token_records << 16, id0, id1}
+//   ids     {id2..id5}, {id6..id9}, ... (pad FZ_QTOK_PAD): the query tokens that exist in the corpus
+//           vocabulary, the only ones that can intersect, in token order
+//   tokens  {4 row bytes, 4 row bytes, 4 row bytes, meta}: up to 12 text symbols of one token, each byte =
+//           4 * (Peq row of the symbol), padded with 0 (row 0 is all zero in every column, so a step on it
+//           changes nothing) up to the 4, 8 or 12 steps of the record's class; meta = class | known << 2 |
+//           last << 3 | first << 4; a longer token continues in the next record.  `known` says the token has
+//           a vocabulary id (it takes one bit, two in the packed kernel, off the lane's "candidate has
+//           this token" string), `last` that the separator step follows (token_set only).  Symbols no
+//           candidate uses are dropped on the host: they cannot change the LCS state.
 #define FZ_STREAM_MAX_TOK 8u      // token slots of an eligible tile
 #define FZ_PK_MAX_TOK 4u          // ... of a tile the packed kernel takes (two tiles per wave, <= 31 symbols together)
 #define FZ_PK_SPLIT_SHIFT 27u     // packed tile list: entry 2i = tile A | split << 27, entry 2i + 1 = tile B
-#define FZ_STREAM_MAX_ROWS 63u    // Peq rows (distinct text symbols of one launch), row byte = 4*row < 256
+#define FZ_STREAM_MAX_ROWS 63u    // Peq rows (the zero row + the distinct text symbols of one launch), row byte = 4*row < 256
+#define FZ_STREAM_MAX_IDS 15u     // known tokens of a streamed query
 #define FZ_STREAM_QUEUES 32u      // work queues of one launch (each a contiguous range of items)
 #define FZ_STREAM_QPAD 64u        // u32 words between two queue counters (256 B: one counter per cache line)
 #define FZ_STREAM_TAB 128u        // score table covers length sums L < 128 ...

@@ -862,7 +862,7 @@ struct QueryBatch {
     std::vector<FzRec> recs;
     std::vector<uint32_t> qrec;
     uint8_t row_of_sym[256];
-    uint32_t nrows = 0;
+    uint32_t nrows = 1;                  // row 0 is never written: the all-zero row that pads a token record
     struct Trip { uint32_t id, pos, len1; };
     std::u32string s_pat;                // scratch of prepare_query, reused from query to query
     std::vector<Trip> s_trips;
@@ -890,21 +890,26 @@ static bool stream_append(QueryBatch &b, bool token_set, uint32_t out_row, uint3
         if (!dup) fresh[nfresh++] = sy;
     }
     if (b.nrows + nfresh > FZ_STREAM_MAX_ROWS + 1u) return false;
-    for (uint32_t i = 0; i < nfresh; ++i) b.row_of_sym[fresh[i]] = (uint8_t)(4u * b.nrows++);
 
-    const size_t hdr = b.recs.size();
-    b.qrec.push_back((uint32_t)hdr);
-    b.recs.push_back(FzRec{out_row, m, 0u, 0u});
-    uint32_t n_ids = 0;
-    if (token_set) {
-        FzRec r{FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD};
+    // header {out_row, m | n_ids << 8 | token records << 16, id0, id1}, then the other known ids four to a record
+    uint32_t known[16], n_ids = 0;
+    if (token_set)
         for (uint32_t id : ids) {
             if (id == FZ_QTOK_UNKNOWN) continue;
-            (&r.x)[n_ids & 3u] = id;
-            if ((++n_ids & 3u) == 0u) { b.recs.push_back(r); r = FzRec{FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD}; }
+            if (n_ids == FZ_STREAM_MAX_IDS) return false;             // two bits per token in a 32-bit lane string
+            known[n_ids++] = id;
         }
-        if (n_ids & 3u) b.recs.push_back(r);
+    for (uint32_t i = 0; i < nfresh; ++i) b.row_of_sym[fresh[i]] = (uint8_t)(4u * b.nrows++);
+    const size_t hdr = b.recs.size();
+    b.qrec.push_back((uint32_t)hdr);
+    b.recs.push_back(FzRec{out_row, 0u, n_ids > 0 ? known[0] : FZ_QTOK_PAD, n_ids > 1 ? known[1] : FZ_QTOK_PAD});
+    for (uint32_t j = 2; j < n_ids; j += 4) {
+        FzRec r{FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD, FZ_QTOK_PAD};
+        for (uint32_t k = 0; k < 4 && j + k < n_ids; ++k) (&r.x)[k] = known[j + k];
+        b.recs.push_back(r);
     }
+    // token records {symbols 0-3, 4-7, 8-11 as row bytes (0 = the all-zero row: padding), class | known << 2 |
+    // last << 3 | first << 4}: the kernel runs 4, 8 or 12 steps by class, so that no branch depends on the length
     uint32_t nrec = 0;
     const size_t ntok = tok_first.size() - 1;
     for (size_t t = 0; t < ntok; ++t) {
@@ -912,20 +917,21 @@ static bool stream_append(QueryBatch &b, bool token_set, uint32_t out_row, uint3
         uint32_t pos = a;
         bool first = true;
         do {                                             // an empty token still owns its separator step
-            const uint32_t n = std::min<uint32_t>(8u, e - pos);
-            FzRec r{first ? ids[t] : FZ_QTOK_CONT, n, 0u, 0u};
+            const uint32_t n = std::min<uint32_t>(12u, e - pos);
+            FzRec r{0u, 0u, 0u, n <= 4u ? 0u : (n <= 8u ? 1u : 2u)};
             for (uint32_t k = 0; k < n; ++k)
-                (k < 4 ? r.z : r.w) |= (uint32_t)b.row_of_sym[text[pos + k]] << (8u * (k & 3u));
+                (&r.x)[k >> 2] |= (uint32_t)b.row_of_sym[text[pos + k]] << (8u * (k & 3u));
             pos += n;
-            if (pos >= e) r.y |= 0x100u;                 // last record of the token
-            if (first) r.y |= 0x200u;
-            if (first && ids[t] != FZ_QTOK_UNKNOWN) r.y |= 0x400u;
+            if (first) r.w |= 16u;
+            if (first && token_set && ids[t] != FZ_QTOK_UNKNOWN) r.w |= 4u;
+            if (pos >= e) r.w |= 8u;                     // last record of the token
             b.recs.push_back(r);
             ++nrec;
             first = false;
         } while (pos < e);
     }
-    b.recs[hdr].z = n_ids | (nrec << 16);
+    if (nrec > 0xFFFFu) { b.recs.resize(hdr); b.qrec.pop_back(); return false; }
+    b.recs[hdr].y = m | (n_ids << 8) | (nrec << 16);
     return true;
 }
 
@@ -1136,7 +1142,7 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
     // the score table covers L < 128; a stream tile holds at most 64 symbols.  token_set looks up
     // L = m + clen - 2, ratio L = m + clen.
     b.stream_max_m = kmode == FZ_MODE_TOKEN_SET ? (FZ_STREAM_TAB + 1u - 64u) : (FZ_STREAM_TAB - 1u - 64u);
-    if (b.allow_stream) { b.recs.reserve((size_t)rows * 8 + 2); b.qrec.reserve(rows); }
+    if (b.allow_stream) { b.recs.reserve((size_t)rows * 6 + 2); b.qrec.reserve(rows); }
     for (uint32_t r = 0; r < rows; ++r) {
         const uint64_t qi = q0 + r;
         if (q_offs[qi + 1] < q_offs[qi]) return fail(FZ_ERR_INVALID, "query offsets not monotone at %llu", (unsigned long long)qi);
@@ -1144,8 +1150,7 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
         if (rc != FZ_OK) return rc;
     }
     const auto t_prep = std::chrono::steady_clock::now();
-    b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches two records ahead
-    b.recs.push_back(FzRec{0, 0, 0, 0});
+    for (int i = 0; i < 8; ++i) b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches a few records ahead
     // one device blob: [FzQuery list][peq][tok_id][tok_pos][tok_len1][stream records][qrec][rows]
     struct Launch { int W; uint32_t first, count; bool slow_only; };
     std::vector<FzQuery> qlist;

@@ -497,6 +497,16 @@ __device__ __forceinline__ uint32_t fz_add3(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+// One Hyyro step of the packed kernel as ONE asm block: u = v & row & mk; v = (v + u + negstop) | (v ^ u).
+// Left as separate statements the compiler pads every consumer of an inline-asm result with an s_nop (it
+// cannot see that the asm holds a plain v_add3), and a nop costs an issue slot like any other instruction.
+__device__ __forceinline__ uint32_t fz_pk_step(uint32_t v, uint32_t row, uint32_t mk, uint32_t negstop)
+{
+    uint32_t u, t;
+    asm("v_bitop3_b32 %1, %0, %3, %4 bitop3:0x80\n\tv_add3_u32 %2, %0, %1, %5\n\tv_bitop3_b32 %0, %2, %0, %1 bitop3:0xf6" : "+v"(v), "=&v"(u), "=&v"(t) : "v"(row), "v"(mk), "s"(negstop));   // EMUL: u = v & row & mk; t = v + u + negstop; v = t | (v ^ u);
+    return v;
+}
+
 // a byte of the rounded-score table: index masked to the table and ORed onto its LDS address in one
 // v_and_or (the table is the first thing in LDS, so its address is a multiple of its size: checked once
 // per block by the packed kernel)
@@ -504,6 +514,25 @@ __device__ __forceinline__ uint32_t fz_tab_load(uint32_t tab_off, uint32_t idx)
 {
     const uint32_t a = (idx & (FZ_STREAM_TAB_BYTES - 1u)) | tab_off;
     return *(__attribute__((address_space(3))) const uint8_t *)(uintptr_t)a;   // EMUL: return *(const uint8_t *)(emul::g_lds + a);
+}
+
+// ---- lane masks: a vector compare leaves one bit per lane in a scalar register pair -------------------
+// Scalar ORs combine them (no lane operation per compare), and two single instructions bring a mask back
+// into the lanes: a select, and "shift the lane's bit into a per-lane bit string" (v_addc: x + x + carry-in).
+__device__ __forceinline__ uint64_t fz_eq_mask(uint32_t a, uint32_t b) { return __ballot(a == b); }
+
+__device__ __forceinline__ uint32_t fz_shift_in(uint32_t bits, uint64_t mask)
+{
+    asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(mask) : "vcc");   // EMUL: bits = (bits << 1) | (uint32_t)((mask >> (threadIdx.x & 63u)) & 1ull);
+    return bits;
+}
+
+// this lane's bit of `mask` set ? a : all ones
+__device__ __forceinline__ uint32_t fz_ones_unless(uint64_t mask, uint32_t a)
+{
+    uint32_t r;
+    asm("v_cndmask_b32 %0, -1, %1, %2" : "=v"(r) : "v"(a), "s"(mask));   // EMUL: r = ((mask >> (threadIdx.x & 63u)) & 1ull) ? a : 0xFFFFFFFFu;
+    return r;
 }
 
 template <int W, int STRIDE>
@@ -523,8 +552,18 @@ __device__ __forceinline__ void fz_stream_step(uint32_t (&V)[W], const uint32_t 
     }
 }
 
-// the query loop of one tile, specialised on the tile's token slots NT (the id compares are unrolled
-// over exactly NT candidate tokens; padding slots hold FZ_TOK_NONE, which no record id equals)
+// The query loop of one tile, specialised on the tile's token slots NT (padding slots hold FZ_TOK_NONE,
+// which no query id equals).  Record stream of one query (fz_common.h, "stream records"):
+//   header   {out_row, m | n_ids << 8 | n_token_records << 16, id0, id1}
+//   ids      {id2..id5}, {id6..id9}, ... while n_ids says so: the query tokens the corpus vocabulary knows
+//   tokens   {4 row bytes, 4 row bytes, 4 row bytes, meta}: up to 12 text symbols of one token, padded with
+//            row 0 (all zero in every column: a step on it changes nothing) up to 4, 8 or 12 steps
+// Phase 1 compares every query id with the NT candidate ids (lane masks, fz_eq_mask): a candidate token the
+// query also has leaves the pattern (its range is cleared in M), and whether the CANDIDATE has query token j
+// is shifted into a per-lane bit string, one bit per known query token, in token order.  Phase 2 scans the
+// tokens: a known token takes its bit off the top of that string and is scanned with an all-zero mask when
+// the bit is set (a token both sides have is in neither difference).  No lane operation depends on the
+// number of symbols: the only scalar branches of a token are its step class and its flags.
 template <int W, int MODE, int STRIDE, int NT>
 __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const FzRec *__restrict__ recs,
                                                   uint8_t *__restrict__ scores, const uint8_t *s_tab,
@@ -537,78 +576,91 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
     uint32_t ri = p.qrec[q0];
-    FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with two padding records
+    FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with padding records
 #define FZ_ADVANCE() do { cur = nxt; nxt = recs[ri + 2u]; ++ri; } while (0)
 
     for (uint32_t q = q0; q < q1; ++q) {
-        // header {out_row, m, n_ids | n_tok_recs << 16, -}
-        const uint32_t out_row = cur.x, m = cur.y;
-        const uint32_t n_ids = cur.z & 0xFFFFu, nrec = cur.z >> 16;
+        const uint32_t out_row = cur.x, m = cur.y & 0xFFu;
+        const uint32_t n_ids = (cur.y >> 8) & 0xFFu, nrec = cur.y >> 16;
+        const uint32_t id0 = cur.z, id1 = cur.w;
         FZ_ADVANCE();
 
-        uint32_t M[W];
+        uint32_t M[W], has = 0u;                         // has: bit string "the candidate has query token j"
 #pragma unroll
         for (int w = 0; w < W; ++w) M[w] = 0xFFFFFFFFu;
-        if (MODE == FZ_MODE_TOKEN_SET) {
-            bool hit[NT];
+        if (MODE == FZ_MODE_TOKEN_SET && n_ids != 0u) {
+            uint64_t hit[NT];
+            {                                                         // id 0: the masks start here
+                uint64_t any = 0ull;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) hit[i] = false;
-            for (uint32_t j = 0; j < n_ids; j += 4u) {
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-                    hit[i] |= (cid[i] == cur.x) | (cid[i] == cur.y) | (cid[i] == cur.z) | (cid[i] == cur.w);
-                FZ_ADVANCE();
+                for (int i = 0; i < NT; ++i) { hit[i] = fz_eq_mask(cid[i], id0); any |= hit[i]; }
+                has = fz_shift_in(has, any);
             }
+#define FZ_NEXT_ID(sj) do { uint64_t any_ = 0ull; _Pragma("unroll") for (int i = 0; i < NT; ++i) { const uint64_t c_ = fz_eq_mask(cid[i], (sj)); hit[i] |= c_; any_ |= c_; } \
+                            has = fz_shift_in(has, any_); } while (0)
+            if (n_ids > 1u) {
+                FZ_NEXT_ID(id1);
+                for (uint32_t j = 2u; j < n_ids; j += 4u) {
+                    const uint32_t ia = cur.x, ib = cur.y, ic = cur.z, id = cur.w;
+                    FZ_ADVANCE();
+                    FZ_NEXT_ID(ia);
+                    if (j + 1u < n_ids) { FZ_NEXT_ID(ib);
+                    if (j + 2u < n_ids) { FZ_NEXT_ID(ic);
+                    if (j + 3u < n_ids) { FZ_NEXT_ID(id); } } }
+                }
+            }
+#undef FZ_NEXT_ID
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int w = 0; w < W; ++w) M[w] &= hit[i] ? ~Rm[i][w] : 0xFFFFFFFFu;
+                for (int w = 0; w < W; ++w) M[w] &= fz_ones_unless(hit[i], ~Rm[i][w]);
+            has <<= 32u - n_ids;                                      // the first token's bit on top
         }
 
         uint32_t V[W], Mk[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) { V[w] = 0xFFFFFFFFu; Mk[w] = M[w]; }
         for (uint32_t r = 0; r < nrec; ++r) {
-            // token record {id, nsym | last << 8 | first << 9 | known << 10, symbols 0-3, symbols 4-7}
-            const uint32_t id = cur.x, meta = cur.y, s03 = cur.z, s47 = cur.w;
-            const uint32_t nsym = meta & 0xFFu;
-            uint32_t row[8][W];
-            {
-                // LDS addresses of the eight rows in this lane's column: column address + symbol byte
-                const uint32_t o[8] = {fz_add_byte<0>(s03, col_off), fz_add_byte<1>(s03, col_off), fz_add_byte<2>(s03, col_off), fz_add_byte<3>(s03, col_off),
-                                       fz_add_byte<0>(s47, col_off), fz_add_byte<1>(s47, col_off), fz_add_byte<2>(s47, col_off), fz_add_byte<3>(s47, col_off)};
+            // token record {symbols 0-3, symbols 4-7, symbols 8-11, class | known << 2 | last << 3 | first << 4}
+            const uint32_t s0 = cur.x, s1 = cur.y, s2 = cur.z, meta = cur.w;
+            if (MODE == FZ_MODE_TOKEN_SET && (meta & 16u)) {
+                if (meta & 4u) {
+                    const uint32_t t = (uint32_t)((int32_t)has >> 31);      // all ones: both sides have the token
+                    has <<= 1;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
+                    for (int w = 0; w < W; ++w) Mk[w] = M[w] & ~t;
+                } else {
 #pragma unroll
-                    for (int w = 0; w < W; ++w)
-                        row[k][w] = fz_lds_load(o[k] + (uint32_t)w * PLANE);
-            }
-            if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x200u)) {
-                bool skip = false;
-                if (meta & 0x400u) {
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) skip |= cid[i] == id;
+                    for (int w = 0; w < W; ++w) Mk[w] = M[w];
                 }
-#pragma unroll
-                for (int w = 0; w < W; ++w) Mk[w] = skip ? 0u : M[w];
             }
-            // all eight rows are in flight before the first guarded step: the empty asm pins them
-            // here, and its memory clobber keeps the next record's scalar load BELOW the wait so that
-            // the load overlaps this record's steps instead of being waited for at once
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-#pragma unroll
-                for (int w = 0; w < W; ++w) asm volatile("" : "+v"(row[k][w]) : : "memory");
-            FZ_ADVANCE();
-            if (nsym > 0u) { fz_stream_step<W, STRIDE>(V, row[0], Mk);
-            if (nsym > 1u) { fz_stream_step<W, STRIDE>(V, row[1], Mk);
-            if (nsym > 2u) { fz_stream_step<W, STRIDE>(V, row[2], Mk);
-            if (nsym > 3u) { fz_stream_step<W, STRIDE>(V, row[3], Mk);
-            if (nsym > 4u) { fz_stream_step<W, STRIDE>(V, row[4], Mk);
-            if (nsym > 5u) { fz_stream_step<W, STRIDE>(V, row[5], Mk);
-            if (nsym > 6u) { fz_stream_step<W, STRIDE>(V, row[6], Mk);
-            if (nsym > 7u) { fz_stream_step<W, STRIDE>(V, row[7], Mk); } } } } } } } }
-            if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x100u)) fz_stream_step<W, STRIDE>(V, psep, Mk);
+            // LDS rows of this lane's column: column address + row byte (one SDWA add each).  All rows of the
+            // record are in flight before its first step: the empty asm pins them there, and its memory
+            // clobber keeps the next record's scalar load BELOW the wait, so that the load overlaps this
+            // record's steps instead of being waited for at once.
+            uint32_t row[12][W];
+#define FZ_ROWS4(g, word) do { const uint32_t o_[4] = {fz_add_byte<0>((word), col_off), fz_add_byte<1>((word), col_off), fz_add_byte<2>((word), col_off), fz_add_byte<3>((word), col_off)}; \
+                               _Pragma("unroll") for (int k = 0; k < 4; ++k) _Pragma("unroll") for (int w = 0; w < W; ++w) row[4 * (g) + k][w] = fz_lds_load(o_[k] + (uint32_t)w * PLANE); } while (0)
+#define FZ_PIN4(g) do { _Pragma("unroll") for (int k = 0; k < 4; ++k) _Pragma("unroll") for (int w = 0; w < W; ++w) asm volatile("" : "+v"(row[4 * (g) + k][w]) : : "memory"); } while (0)
+#define FZ_STEPS4(g) do { _Pragma("unroll") for (int k = 0; k < 4; ++k) fz_stream_step<W, STRIDE>(V, row[4 * (g) + k], Mk); } while (0)
+            const uint32_t cls = meta & 3u;
+            if (cls == 0u) {
+                FZ_ROWS4(0, s0); FZ_PIN4(0);
+                FZ_ADVANCE();
+                FZ_STEPS4(0);
+            } else if (cls == 1u) {
+                FZ_ROWS4(0, s0); FZ_ROWS4(1, s1); FZ_PIN4(0); FZ_PIN4(1);
+                FZ_ADVANCE();
+                FZ_STEPS4(0); FZ_STEPS4(1);
+            } else {
+                FZ_ROWS4(0, s0); FZ_ROWS4(1, s1); FZ_ROWS4(2, s2); FZ_PIN4(0); FZ_PIN4(1); FZ_PIN4(2);
+                FZ_ADVANCE();
+                FZ_STEPS4(0); FZ_STEPS4(1); FZ_STEPS4(2);
+            }
+#undef FZ_ROWS4
+#undef FZ_PIN4
+#undef FZ_STEPS4
+            if (MODE == FZ_MODE_TOKEN_SET && (meta & 8u)) fz_stream_step<W, STRIDE>(V, psep, Mk);
         }
 
         uint32_t lcs = 0u;
@@ -788,79 +840,99 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
     // + (m & clen & 1), so every table index is a per-tile lane constant + a per-query scalar + popcounts.
     // The empty asm keeps the constants as they are (the compiler would re-derive them per query).
     const uint32_t tab_off = fz_lds_addr(s_tab);
-    uint32_t c_tab[2], c_odd[2], c_len1[2];
+    uint32_t c_tab[2], c_odd[2], c_len1[2], nRm[2][NT], fm[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         c_tab[h] = MODE == FZ_MODE_TOKEN_SET ? ((clen[h] - 2u) << 6) + (clen[h] >> 1) - 2u * fw[h]
                                              : (clen[h] << 6) + (clen[h] >> 1) - fw[h];
         c_odd[h] = clen[h] & 1u;
         c_len1[h] = clen[h] + fw[h] - 2u;
-        asm volatile("" : "+v"(c_tab[h]), "+v"(c_odd[h]), "+v"(c_len1[h]));
+        fm[h] = fmask[h];                                 // in a lane register: a scalar operand costs a vector
+        asm volatile("" : "+v"(c_tab[h]), "+v"(c_odd[h]), "+v"(c_len1[h]), "+v"(fm[h]));   // instruction an issue cycle
+#pragma unroll
+        for (int i = 0; i < NT; ++i) nRm[h][i] = ~Rm[h][i];
     }
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
     uint32_t ri = p.qrec[q0];
-    FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with two padding records
+    FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with padding records
 #define FZ_ADVANCE() do { cur = nxt; nxt = recs[ri + 2u]; ++ri; } while (0)
 
     for (uint32_t q = q0; q < q1; ++q) {
-        const uint32_t out_row = cur.x, m = cur.y;
-        const uint32_t n_ids = cur.z & 0xFFFFu, nrec = cur.z >> 16;
+        // record formats and the two phases: fz_stream_queries above; here every query token leaves TWO
+        // bits in the lane's bit string, "tile A's candidate has it" and "tile B's candidate has it"
+        const uint32_t out_row = cur.x, m = cur.y & 0xFFu;
+        const uint32_t n_ids = (cur.y >> 8) & 0xFFu, nrec = cur.y >> 16;
+        const uint32_t id0 = cur.z, id1 = cur.w;
         FZ_ADVANCE();
 
-        uint32_t M = 0xFFFFFFFFu;
-        if (MODE == FZ_MODE_TOKEN_SET) {
-            // a candidate token the query also has leaves the pattern: its range is cleared in M at once
-            // (no per-token lane masks to carry through the loop: sixteen of them would not fit the SGPRs)
-#pragma nounroll                                       // unrolled, its compare masks spill (52 bytes of scratch)
-            for (uint32_t j = 0; j < n_ids; j += 4u) {
+        uint32_t M = 0xFFFFFFFFu, has = 0u;
+        if (MODE == FZ_MODE_TOKEN_SET && n_ids != 0u) {
+            uint64_t hit[2][NT];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {                             // id 0: the masks start here
+                uint64_t any = 0ull;
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) {
-                        const bool c = (cid[h][i] == cur.x) | (cid[h][i] == cur.y) | (cid[h][i] == cur.z) | (cid[h][i] == cur.w);
-                        M &= c ? ~Rm[h][i] : 0xFFFFFFFFu;
-                    }
-                FZ_ADVANCE();
+                for (int i = 0; i < NT; ++i) { hit[h][i] = fz_eq_mask(cid[h][i], id0); any |= hit[h][i]; }
+                has = fz_shift_in(has, any);
             }
+#define FZ_NEXT_ID(sj) do { _Pragma("unroll") for (int h = 0; h < 2; ++h) { uint64_t any_ = 0ull; \
+                                _Pragma("unroll") for (int i = 0; i < NT; ++i) { const uint64_t c_ = fz_eq_mask(cid[h][i], (sj)); hit[h][i] |= c_; any_ |= c_; } \
+                                has = fz_shift_in(has, any_); } } while (0)
+            if (n_ids > 1u) {
+                FZ_NEXT_ID(id1);
+                for (uint32_t j = 2u; j < n_ids; j += 4u) {
+                    const uint32_t ia = cur.x, ib = cur.y, ic = cur.z, id = cur.w;
+                    FZ_ADVANCE();
+                    FZ_NEXT_ID(ia);
+                    if (j + 1u < n_ids) { FZ_NEXT_ID(ib);
+                    if (j + 2u < n_ids) { FZ_NEXT_ID(ic);
+                    if (j + 3u < n_ids) { FZ_NEXT_ID(id); } } }
+                }
+            }
+#undef FZ_NEXT_ID
+            // a candidate token the query also has leaves the pattern: its range is cleared in M
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) M &= fz_ones_unless(hit[h][i], nRm[h][i]);
+            has <<= 32u - 2u * n_ids;                                 // the first token's two bits on top
         }
 
         uint32_t V = 0xFFFFFFFFu, Mk = M;
         for (uint32_t r = 0; r < nrec; ++r) {
-            const uint32_t id = cur.x, meta = cur.y, s03 = cur.z, s47 = cur.w;
-            const uint32_t nsym = meta & 0xFFu;
-            uint32_t row[8];
-            {
-                const uint32_t o[8] = {fz_add_byte<0>(s03, col_off), fz_add_byte<1>(s03, col_off), fz_add_byte<2>(s03, col_off), fz_add_byte<3>(s03, col_off),
-                                       fz_add_byte<0>(s47, col_off), fz_add_byte<1>(s47, col_off), fz_add_byte<2>(s47, col_off), fz_add_byte<3>(s47, col_off)};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) row[k] = fz_lds_load(o[k]);
+            const uint32_t s0 = cur.x, s1 = cur.y, s2 = cur.z, meta = cur.w;
+            // the mask of the token (issued between the row reads and the wait for them): a token both sides
+            // have is scanned with a zero mask, per half: Mk = M & ~(tA & fieldA) & ~(tB & fieldB)
+#define FZ_MK() do { if (MODE == FZ_MODE_TOKEN_SET && (meta & 16u)) { \
+                         if (meta & 4u) { const uint32_t tA = (uint32_t)((int32_t)has >> 31), tB = (uint32_t)((int32_t)(has << 1) >> 31); has <<= 2; \
+                                          Mk = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(M, tA, fm[0], 0x70), tB, fm[1], 0x70); } \
+                         else Mk = M; } } while (0)
+            uint32_t row[12];
+#define FZ_ROWS4(g, word) do { const uint32_t o_[4] = {fz_add_byte<0>((word), col_off), fz_add_byte<1>((word), col_off), fz_add_byte<2>((word), col_off), fz_add_byte<3>((word), col_off)}; \
+                               _Pragma("unroll") for (int k = 0; k < 4; ++k) row[4 * (g) + k] = fz_lds_load(o_[k]); } while (0)
+#define FZ_PIN4(g) do { _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(row[4 * (g) + k]) : : "memory"); } while (0)
+#define FZ_PK_STEP(rw) do { V = fz_pk_step(V, (rw), Mk, negstop); } while (0)
+#define FZ_STEPS4(g) do { FZ_PK_STEP(row[4 * (g)]); FZ_PK_STEP(row[4 * (g) + 1]); FZ_PK_STEP(row[4 * (g) + 2]); FZ_PK_STEP(row[4 * (g) + 3]); } while (0)
+            const uint32_t cls = meta & 3u;
+            if (cls == 0u) {
+                FZ_ROWS4(0, s0); FZ_MK(); FZ_PIN4(0);
+                FZ_ADVANCE();
+                FZ_STEPS4(0);
+            } else if (cls == 1u) {
+                FZ_ROWS4(0, s0); FZ_ROWS4(1, s1); FZ_MK(); FZ_PIN4(0); FZ_PIN4(1);
+                FZ_ADVANCE();
+                FZ_STEPS4(0); FZ_STEPS4(1);
+            } else {
+                FZ_ROWS4(0, s0); FZ_ROWS4(1, s1); FZ_ROWS4(2, s2); FZ_MK(); FZ_PIN4(0); FZ_PIN4(1); FZ_PIN4(2);
+                FZ_ADVANCE();
+                FZ_STEPS4(0); FZ_STEPS4(1); FZ_STEPS4(2);
             }
-            if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x200u)) {
-                // a token both sides have is scanned with a zero mask, per half
-                bool skip[2] = {false, false};
-                if (meta & 0x400u) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int i = 0; i < NT; ++i) skip[h] |= cid[h][i] == id;
-                }
-                Mk = M & (skip[0] ? ~fmask[0] : 0xFFFFFFFFu) & (skip[1] ? ~fmask[1] : 0xFFFFFFFFu);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(row[k]) : : "memory");
-            FZ_ADVANCE();
-#define FZ_PK_STEP(rw) do { const uint32_t v_ = V; const uint32_t u_ = __builtin_amdgcn_bitop3_b32(v_, (rw), Mk, 0x80); \
-                            V = __builtin_amdgcn_bitop3_b32(fz_add3(v_, u_, negstop), v_, u_, 0xF6); } while (0)
-            if (nsym > 0u) { FZ_PK_STEP(row[0]);
-            if (nsym > 1u) { FZ_PK_STEP(row[1]);
-            if (nsym > 2u) { FZ_PK_STEP(row[2]);
-            if (nsym > 3u) { FZ_PK_STEP(row[3]);
-            if (nsym > 4u) { FZ_PK_STEP(row[4]);
-            if (nsym > 5u) { FZ_PK_STEP(row[5]);
-            if (nsym > 6u) { FZ_PK_STEP(row[6]);
-            if (nsym > 7u) { FZ_PK_STEP(row[7]); } } } } } } } }
-            if (MODE == FZ_MODE_TOKEN_SET && (meta & 0x100u)) FZ_PK_STEP(psep);
+            if (MODE == FZ_MODE_TOKEN_SET && (meta & 8u)) FZ_PK_STEP(psep);
+#undef FZ_MK
+#undef FZ_ROWS4
+#undef FZ_PIN4
+#undef FZ_STEPS4
 #undef FZ_PK_STEP
         }
 
@@ -868,14 +940,14 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
         const uint32_t qs = (m << 6) + (m >> 1), m_odd = 0u - (m & 1u);          // scalars
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint32_t bv = (uint32_t)__builtin_popcount(V & fmask[h]);
+            const uint32_t bv = (uint32_t)__builtin_popcount(V & fm[h]);
             const uint32_t both_odd = c_odd[h] & m_odd;
             uint32_t sc;
             if (MODE == FZ_MODE_TOKEN_SET) {
                 //   r0 = T[m + clen - 2][(m + clen - 2*(sect1 + lcs)) >> 1]      (the joined differences)
                 //   r1 = T[sect1 + mn - 2][(mn - sect1) >> 1], mn = min(m, clen)  (intersection vs intersection +
                 //        shorter difference; 100 when one side is contained in the other), used when sect1 > 0
-                const uint32_t bm = (uint32_t)__builtin_popcount(M & fmask[h]);
+                const uint32_t bm = (uint32_t)__builtin_popcount(M & fm[h]);
                 uint32_t r0 = fz_tab_load(tab_off, c_tab[h] + both_odd + qs + bm + bv);
                 const uint32_t m1 = m + fw[h] - 2u;                                      // scalar
                 const uint32_t mn1 = m1 < c_len1[h] ? m1 : c_len1[h];                    // mn + fw - 2
