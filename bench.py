@@ -322,6 +322,12 @@ def main():
             roof["salu_insts_per_step"] = pmc.get("score_insts_salu_per_step")
             if roof["peak"]:
                 roof["frac"] = roof["achieved"] / roof["peak"]
+                # every wave instruction (vector, scalar, LDS, memory) takes an issue slot of its SIMD: the same
+                # ratio over ALL instructions says how full the issue slots are, bookkeeping included
+                if pmc.get("score_insts_all_per_step"):
+                    roof["all_instructions_G_per_s"] = pmc["score_insts_all_per_step"] / score_s / 1e9
+                    roof["issue_slots_frac"] = roof["all_instructions_G_per_s"] / roof["peak"]
+            roof["wave_cycles_waiting_frac"] = pmc.get("score_wave_cycles_waiting_frac")
         else:
             roof["why_null"] = pmc_why
         # ---- the declared roofline: HBM.  Real traffic against the peak is the fraction;

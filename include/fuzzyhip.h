@@ -88,6 +88,8 @@ typedef struct {
     uint32_t select_launches;
     uint64_t pairs;     /* query x candidate pairs scored by the last call */
     double host_prep_ms;/* wall time spent building query tables on the host */
+    uint32_t fused;     /* 1: the last top-k call ran fused (sample + append lists, no score matrix over the shard) */
+    uint32_t fused_fallback_chunks; /* chunks of that call redone through the score matrix (list overflow) */
 } fz_timing;
 
 /* library version (FZ_VERSION of the build) */

@@ -83,7 +83,7 @@ def test_packed_short_tiles(oracle, runner, tmp_path):
                                                             cand[17] + " " + cand[40]]
     for sk, orc in ((0, oracle.TOKEN_SET), (1, oracle.RATIO), (2, oracle.TOKEN_SORT)):
         got = _run(runner, tmp_path, 0, sk, cand, queries, env={"FUZZYHIP_TRACE": "1"})
-        assert "7 tiles -> packed 6, stream1 1," in _run.last_stderr, _run.last_stderr[-500:]
+        assert "7 tiles" in _run.last_stderr and "-> packed 6, stream1 1," in _run.last_stderr, _run.last_stderr[-500:]
         exp = _oracle_scores(oracle, orc, queries, cand)
         bad = np.argwhere(got != exp)
         assert bad.size == 0, (sk, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])
@@ -155,6 +155,27 @@ def test_topk_under_ties(oracle, runner, tmp_path):
             exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, ms, k)
             got = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
             assert got == exp, (k, ms, q, got[:5], exp[:5])
+
+
+def test_fused_topk_sample_and_lists(oracle, runner, tmp_path):
+    """the fused top-k path (sample tiles -> limit per row -> appended lists -> merge) and the slab-major
+    item order, forced onto a small corpus: every 2nd tile is a sample tile, slabs of 1 KB; token_set over
+    the stream kernels, partial_ratio over the general kernel, a many-ties row, k up to the fused limit"""
+    env = {"FUZZYHIP_SAMPLE_MIN_TILES": "4", "FUZZYHIP_SAMPLE_EVERY": "2", "FUZZYHIP_SLAB_KB": "1", "FUZZYHIP_FUSED_MIN_MB": "0",
+           "FUZZYHIP_TRACE": "1"}
+    cps_a, offs_a = synth.make_corpus(420, max_chars=14, seed=61, vocab_size=40, max_tokens=4)
+    cps_b, offs_b = synth.make_corpus(330, max_chars=64, seed=62, vocab_size=40)
+    cand = synth.to_strings(cps_a, offs_a) + synth.to_strings(cps_b, offs_b) + ["x" * 70, "ab " * 30]
+    queries = synth.make_queries(cps_a, offs_a, 4, seed=63) + synth.make_queries(cps_b, offs_b, 3, seed=64)
+    queries += [cand[0].split()[0], "", "y" * 70]
+    buf, o = oracle.pack(cand)
+    for sk, orc, k, ms in ((0, oracle.TOKEN_SET, 10, 35), (0, oracle.TOKEN_SET, 64, 0), (3, oracle.PARTIAL, 7, 50)):
+        idx, score, cnt = _run(runner, tmp_path, 2, sk, cand, queries, min_score=ms, k=k, env=env)
+        assert "fused top-k over %d rows" % len(queries) in _run.last_stderr, _run.last_stderr[-500:]
+        for qi, q in enumerate(queries):
+            exp = oracle.topk(orc, q, buf, o, ms, k)
+            got = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
+            assert got == exp, (sk, k, ms, q, got[:5], exp[:5])
 
 
 def test_topk_many_ties_walk(oracle, runner, tmp_path):

@@ -36,7 +36,8 @@ class FzInfo(ctypes.Structure):
 class FzTiming(ctypes.Structure):
     _fields_ = [("score_ms", ctypes.c_float), ("select_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("score_launches", ctypes.c_uint32), ("select_launches", ctypes.c_uint32),
-                ("pairs", ctypes.c_uint64), ("host_prep_ms", ctypes.c_double)]
+                ("pairs", ctypes.c_uint64), ("host_prep_ms", ctypes.c_double),
+                ("fused", ctypes.c_uint32), ("fused_fallback_chunks", ctypes.c_uint32)]
 
 
 # every symbol include/fuzzyhip.h declares: name -> (restype, argtypes)

@@ -15,6 +15,9 @@
 #define FZ_MODE_NHITS 5
 #define FZ_MODE_FIND 6
 #define FZ_IDX_BITS 40
+#define FZ_EMIT_CAP 2048u          // keys a row can append in the fused top-k path (about 10x what a 1-in-16 sample leaves at k = 64)
+#define FZ_FUSED_MAX_K 64u         // larger k goes through the score matrix
+#define FZ_FUSED_MAX_CHUNKS 1024u  // overflow counters of one fused call
 #define FZ_GRID_Y_MAX 65535u   // rows of one launch that indexes them by blockIdx.y
 #define FZ_IDX_MASK ((1ull << FZ_IDX_BITS) - 1ull)
 
@@ -45,6 +48,23 @@ struct FzTies {
     uint64_t lo, hi;
 };
 
+// ---- fused threshold + top-k (phase 2 of a top-k call) ---------------------------------------------
+// A top-k call first scores the SAMPLE tiles of the view (every 16th tile of the length-sorted order, kept
+// in front of the physical order) into a small score matrix and selects its top-k; that fixes, per query,
+// a lower limit `lim` no result can fall below: the k-th best sample key + 1, or min_score << 40 while the
+// sample holds fewer than k passing candidates.  The other tiles are then scored WITHOUT a score matrix: a
+// lane whose key (score << 40 | 2^40-1 - global index) reaches the limit appends it to the query's list,
+// and a last kernel merges list and sample keys.  A list that overflows its capacity is reported and the
+// call falls back to the score matrix for that chunk, so the result is exact in every case.
+struct FzEmit {
+    const uint64_t *lim;          // [rows] smallest key that can still be a result; null: store scores instead
+    uint64_t *list;               // [rows][cap] appended keys
+    uint32_t *cnt;                // [rows] appended so far (may run past cap: overflow)
+    uint32_t cap;
+    const uint32_t *orig_of_phys; // physical position -> original index (0xFFFFFFFF: padding lane)
+    uint64_t base_index;
+};
+
 struct FzScoreParams {
     const uint32_t *sym;
     const uint32_t *tokid;
@@ -58,7 +78,8 @@ struct FzScoreParams {
     uint32_t pmax;            // capacity of the per-query token arrays in LDS
     uint32_t ntkw;            // text keep-mask words per lane (ceil(max ndw / 8))
     uint32_t nwaves;          // waves per block
-    const uint32_t *tile_list;// optional: indices of the tiles to cover (null = 0..ntiles-1)
+    const uint32_t *tile_list;// optional: indices of the tiles to cover (null = tile_base .. tile_base+ntiles-1)
+    uint32_t tile_base;
     const FzQuery *queries;   // queries of this launch (blockIdx.y indexes it)
     const uint32_t *qblob;    // Peq tables
     const uint32_t *qtok_id;
@@ -67,6 +88,7 @@ struct FzScoreParams {
     uint8_t *scores;          // [rows][row_stride]
     uint64_t row_stride;
     FzTies ties;
+    FzEmit emit;
 };
 
 // ---- stream kernel (fz_score_stream): short candidates as per-lane patterns, queries as text -----
@@ -108,7 +130,11 @@ struct FzStreamParams {
     uint32_t stride;           // dwords per lane of one Peq table word plane (odd, > max row)
     uint32_t nq;               // queries of this launch
     uint32_t q_per_block;      // queries per group
-    uint32_t nitems;           // work items = ntiles * query groups, numbered group-major
+    uint32_t nitems;           // work items = units (tiles or tile pairs) * query groups, numbered slab-major:
+                               // all query groups over the first slab_units units, then over the next slab, ...
+    uint32_t slab_units;       // units per slab: a slab's symbols, ids and ends stay cache resident while every
+                               // query group passes over it (a shard larger than the Infinity Cache is otherwise
+                               // re-streamed from HBM once per group)
     uint32_t grid_blocks;      // persistent blocks to launch (the chip's CU count x blocks per CU)
     uint32_t chunk;            // items a wave draws at a time (1..64)
     uint32_t *work_counter;    // FZ_STREAM_QUEUES device counters FZ_STREAM_QPAD words apart, zero before the launch
@@ -118,20 +144,24 @@ struct FzStreamParams {
     const uint8_t *score_tab;  // [128*64] rounded ratio T[L*64 + (d >> 1)], d of L's parity
     uint8_t *scores;
     uint32_t row_stride;       // bytes per score row (< 2^32)
+    FzEmit emit;
 };
 
 struct FzSelectParams {
     const uint8_t *scores;
     uint64_t row_stride;
-    uint32_t n;               // valid candidates (physical positions >= n are padding)
+    uint32_t n;               // physical positions of a row that hold candidates (positions >= n are padding or absent)
+    uint32_t n_orig;          // original indices of the view (the walk in original order skips those whose position is >= n)
     const uint32_t *orig_of_phys;
     const uint32_t *phys_of_orig;
+    const uint32_t *walk;     // optional [n]: the original indices of the row's candidates, ascending (null: 0..n_orig-1)
     int32_t min_score;
     uint32_t k;
     uint64_t base_index;
     uint64_t *out_keys;       // [rows][k]
     uint32_t *out_cnt;        // [rows] or null
     uint32_t flat;            // 1: every passing score counts as min_score, so the order is by index only
+    uint64_t *out_lim;        // [rows] or null: the limit the row's result sets for the tiles not in it (FzEmit)
     uint64_t *dbg;            // diagnostics (FUZZYHIP_SELECT_DEBUG=1): [rows][8] phase timestamps, or null
 };
 
@@ -159,4 +189,15 @@ struct FzSelect16Params {
     uint64_t base_index;
     uint64_t *out_keys;           // [rows][k]: (rank << 40) | (2^40-1 - global index), 0 = padding
     uint32_t *out_cnt;
+};
+
+// merge of the sample's top-k keys with the appended lists (fz_merge_lists)
+struct FzMergeParams {
+    const uint64_t *sample_keys;  // [rows][k], 0-padded
+    const uint64_t *list;         // [rows][cap]
+    const uint32_t *cnt;          // [rows]
+    uint32_t cap, k;
+    uint64_t *out_keys;           // [rows][k]; may alias sample_keys
+    uint32_t *out_cnt;            // [rows] or null
+    uint32_t *overflow;           // one counter: rows whose list ran past cap
 };

@@ -36,6 +36,9 @@ hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_
 hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st);
 hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_t st);
 hipError_t fz_launch_select16(const FzSelect16Params &p, uint32_t rows, hipStream_t st);
+hipError_t fz_launch_merge(const FzMergeParams &p, uint32_t rows, hipStream_t st);
+hipError_t fz_launch_unpermute(const void *in, uint64_t in_stride, void *out, uint64_t out_stride, const uint32_t *phys_of_orig,
+                               uint32_t n, uint32_t rows, uint32_t elem_bytes, hipStream_t st);
 hipError_t fz_scratch_acquire(int device, void **ptr, size_t *bytes);
 
 // ---------------------------------------------------------------------------------------------
@@ -140,12 +143,17 @@ struct View {
     uint64_t n_sym_words = 0, n_tok_slots = 0;            // lengths of d_sym and d_tokid / d_tokend
     std::vector<uint16_t> sym_of_cp;                      // code point -> symbol (0 = not in corpus)
     uint32_t *d_sym = nullptr, *d_tokid = nullptr, *d_orig_of_phys = nullptr, *d_phys_of_orig = nullptr;
+    uint32_t *d_sample_walk = nullptr;                    // original indices of the sample candidates, ascending
     uint16_t *d_tokend = nullptr;
     FzTile *d_tiles = nullptr;
     // tile indices by kernel: stream kernel with 1 / 2 pattern words, general kernel for the rest
     // (s0: candidates of at most 15 symbols, taken two tiles at a time by the packed stream kernel)
     uint32_t *d_tiles_s0 = nullptr, *d_tiles_s1 = nullptr, *d_tiles_s2 = nullptr, *d_tiles_slow = nullptr;
     uint32_t n_s0 = 0, n_s1 = 0, n_s2 = 0, n_slow = 0;
+    // Sample tiles (every FZ sample_every-th tile of the length-sorted order) hold the physical positions
+    // [0, n_sample_tiles * 64); each tile list holds its sample entries first (ns_*).  n_sample_tiles ==
+    // ntiles: no split (small shards), every top-k call goes through the score matrix.
+    uint32_t n_sample_tiles = 0, ns_s0 = 0, ns_s1 = 0, ns_s2 = 0, ns_slow = 0;
     std::vector<uint32_t> h_orig_of_phys;
 };
 
@@ -191,6 +199,9 @@ struct fz_corpus {
     uint16_t *d_ranks = nullptr; size_t ranks_cap = 0;    // fz_query_topk_pair: combined ranks, rank table
     uint16_t *d_rank_tab = nullptr; size_t rank_tab_cap = 0;
     bool use_stream = true;                               // FUZZYHIP_NO_STREAM=1 forces the general kernel
+    bool use_fused = true;                                // FUZZYHIP_NO_FUSED=1: every top-k call through the score matrix
+    uint64_t fused_min_bytes = 64ull << 20;               // FUZZYHIP_FUSED_MIN_MB: smaller score matrices are simply written (fewer launches)
+    uint64_t slab_bytes = 24ull << 20;                    // FUZZYHIP_SLAB_KB: corpus bytes one stream kernel keeps cache resident
     uint32_t stream_oversub = 1;                          // FUZZYHIP_STREAM_OVERSUB: persistent blocks per slot
     uint32_t pipe_chunks = 1;                             // FUZZYHIP_CHUNKS: pieces of a large top-k batch
     uint32_t stream_waves = 16, stream_blocks = 3072;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
@@ -277,7 +288,7 @@ extern "C" int fz_device_count(int *out_n)
 static void free_view(View &v)
 {
     for (void *p : {(void *)v.d_sym, (void *)v.d_tokid, (void *)v.d_tokend, (void *)v.d_tiles,
-                    (void *)v.d_orig_of_phys, (void *)v.d_phys_of_orig, (void *)v.d_tiles_s0, (void *)v.d_tiles_s1,
+                    (void *)v.d_orig_of_phys, (void *)v.d_phys_of_orig, (void *)v.d_sample_walk, (void *)v.d_tiles_s0, (void *)v.d_tiles_s1,
                     (void *)v.d_tiles_s2, (void *)v.d_tiles_slow})
         if (p) (void)hipFree(p);
     v = View();
@@ -310,42 +321,56 @@ static int upload_tile_lists(View &v, const std::vector<FzTile> &tiles, const st
 {
     std::vector<uint32_t> ts0, ts1, ts2, tslow;
     const bool pack = getenv("FUZZYHIP_NO_PACK") == nullptr;      // experiments: keep short tiles in the plain kernel
-    // Packed pairs: two tiles whose longest candidates have 31 symbols or fewer TOGETHER share one
-    // pattern word per lane (tile A below the split, tile B above it).  Tiles are sorted by their longest
-    // candidate and the shortest is paired with the longest that still fits; a tile that finds no
-    // partner stays with the one-tile kernel.
-    std::vector<uint8_t> paired(v.ntiles, 0);
-    if (pack && !v.wide && v.ntiles < (1u << FZ_PK_SPLIT_SHIFT)) {
-        std::vector<uint32_t> el;
-        for (uint32_t t = 0; t < v.ntiles; ++t)
-            if (tiles[t].ntok <= FZ_PK_MAX_TOK && tile_maxlen[t] <= 29u) el.push_back(t);
-        std::stable_sort(el.begin(), el.end(), [&](uint32_t a, uint32_t b) { return tile_maxlen[a] < tile_maxlen[b]; });
-        size_t lo = 0, hi = el.size();
-        while (lo + 1 < hi) {
-            const uint32_t a = el[lo], b = el[hi - 1];
-            if (tile_maxlen[a] + tile_maxlen[b] <= 31u) {
-                ts0.push_back(a | (tile_maxlen[a] << FZ_PK_SPLIT_SHIFT));      // split = field width of tile A
-                ts0.push_back(b);
-                paired[a] = paired[b] = 1;
-                ++lo; --hi;
-            } else {
-                --hi;                                                         // too long for any partner left
+    if (v.n_sample_tiles == 0 || v.n_sample_tiles > v.ntiles) v.n_sample_tiles = v.ntiles;
+    // the sample tiles [0, n_sample_tiles) and the others are listed (and paired) separately, sample first
+    for (int part = 0; part < 2; ++part) {
+        const uint32_t t_lo = part == 0 ? 0u : v.n_sample_tiles, t_hi = part == 0 ? v.n_sample_tiles : v.ntiles;
+        // Packed pairs: two tiles whose longest candidates have 31 symbols or fewer TOGETHER share one
+        // pattern word per lane (tile A below the split, tile B above it).  Tiles are sorted by their longest
+        // candidate and the shortest is paired with the longest that still fits; a tile that finds no
+        // partner stays with the one-tile kernel.
+        std::vector<uint8_t> paired(v.ntiles, 0);
+        if (pack && !v.wide && v.ntiles < (1u << FZ_PK_SPLIT_SHIFT)) {
+            std::vector<uint32_t> el;
+            for (uint32_t t = t_lo; t < t_hi; ++t)
+                if (tiles[t].ntok <= FZ_PK_MAX_TOK && tile_maxlen[t] <= 29u) el.push_back(t);
+            std::stable_sort(el.begin(), el.end(), [&](uint32_t a, uint32_t b) { return tile_maxlen[a] < tile_maxlen[b]; });
+            size_t lo = 0, hi = el.size();
+            while (lo + 1 < hi) {
+                const uint32_t a = el[lo], b = el[hi - 1];
+                if (tile_maxlen[a] + tile_maxlen[b] <= 31u) {
+                    ts0.push_back(a | (tile_maxlen[a] << FZ_PK_SPLIT_SHIFT));      // split = field width of tile A
+                    ts0.push_back(b);
+                    paired[a] = paired[b] = 1;
+                    ++lo; --hi;
+                } else {
+                    --hi;                                                         // too long for any partner left
+                }
             }
         }
-    }
-    for (uint32_t t = 0; t < v.ntiles; ++t) {
-        // the stream kernel keeps one Peq row per symbol byte: 8-bit symbols only
-        if (paired[t]) continue;
-        if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
-        else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
-        else tslow.push_back(t);
+        for (uint32_t t = t_lo; t < t_hi; ++t) {
+            // the stream kernel keeps one Peq row per symbol byte: 8-bit symbols only
+            if (paired[t]) continue;
+            if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 8u) ts1.push_back(t);
+            else if (!v.wide && tiles[t].ntok <= FZ_STREAM_MAX_TOK && tiles[t].ndw <= 16u) ts2.push_back(t);
+            else tslow.push_back(t);
+        }
+        if (part == 0) {
+            v.ns_s0 = (uint32_t)ts0.size(); v.ns_s1 = (uint32_t)ts1.size();
+            v.ns_s2 = (uint32_t)ts2.size(); v.ns_slow = (uint32_t)tslow.size();
+        }
     }
     v.n_s0 = (uint32_t)ts0.size();
     v.n_s1 = (uint32_t)ts1.size(); v.n_s2 = (uint32_t)ts2.size(); v.n_slow = (uint32_t)tslow.size();
     if (getenv("FUZZYHIP_TRACE"))
-        fprintf(stderr, "fuzzyhip: %u tiles -> packed %u, stream1 %u, stream2 %u, general %u\n",
-                v.ntiles, v.n_s0, v.n_s1, v.n_s2, v.n_slow);
+        fprintf(stderr, "fuzzyhip: %u tiles (%u sample) -> packed %u, stream1 %u, stream2 %u, general %u\n",
+                v.ntiles, v.n_sample_tiles, v.n_s0, v.n_s1, v.n_s2, v.n_slow);
     int rc;
+    if (v.n_sample_tiles < v.ntiles) {
+        std::vector<uint32_t> walk(v.h_orig_of_phys.begin(), v.h_orig_of_phys.begin() + (size_t)v.n_sample_tiles * FZ_TILE);
+        std::sort(walk.begin(), walk.end());
+        if ((rc = upload(&v.d_sample_walk, walk, &v.device_bytes)) != FZ_OK) return rc;
+    }
     if ((rc = upload(&v.d_tiles_s0, ts0, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_tiles_s1, ts1, &v.device_bytes)) != FZ_OK) return rc;
     if ((rc = upload(&v.d_tiles_s2, ts2, &v.device_bytes)) != FZ_OK) return rc;
@@ -445,6 +470,32 @@ static int build_view(fz_corpus *c, int kind)
         keys[i] = (len << 48) | (std::min<uint64_t>(nt, 0xFFFF) << 32) | i;
     }
     std::sort(keys.begin(), keys.end());
+    // Large shards keep a SAMPLE in front of the physical order: every `every`-th tile of the sorted order
+    // (so the sample has the length distribution of the shard).  A fused top-k call scores it first; its
+    // k-th best key is the limit the other tiles' candidates must reach (FzEmit, fz_common.h).  The last
+    // tile may be partly padding and stays last.
+    v.n_sample_tiles = v.ntiles;
+    {
+        uint32_t every = 16, min_tiles = 256;
+        if (const char *e = getenv("FUZZYHIP_SAMPLE_EVERY")) every = (uint32_t)std::max(0, atoi(e));
+        if (const char *e = getenv("FUZZYHIP_SAMPLE_MIN_TILES")) min_tiles = (uint32_t)std::max(2, atoi(e));
+        if (every >= 2 && v.ntiles >= min_tiles) {
+            std::vector<uint64_t> front, back;
+            front.reserve(n / every + FZ_TILE); back.reserve(n);
+            uint32_t ns = 0;
+            for (uint32_t t = 0; t < v.ntiles; ++t) {
+                const uint64_t lo = (uint64_t)t * FZ_TILE, hi = std::min<uint64_t>(n, lo + FZ_TILE);
+                const bool sample = t % every == every / 2 && t + 1 != v.ntiles;
+                (sample ? front : back).insert((sample ? front : back).end(), keys.begin() + lo, keys.begin() + hi);
+                ns += sample ? 1u : 0u;
+            }
+            if (ns != 0) {
+                front.insert(front.end(), back.begin(), back.end());
+                keys.swap(front);
+                v.n_sample_tiles = ns;
+            }
+        }
+    }
     v.h_orig_of_phys.assign(v.npad, 0xFFFFFFFFu);
     std::vector<uint32_t> phys_of_orig(n);
     for (uint64_t ph = 0; ph < n; ++ph) {
@@ -557,6 +608,9 @@ static int finish_create(fz_corpus *c)
     }
     if (rc != FZ_OK) return rc;
     if (const char *e = getenv("FUZZYHIP_NO_STREAM")) c->use_stream = !(e[0] == '1');
+    if (const char *e = getenv("FUZZYHIP_NO_FUSED")) c->use_fused = !(e[0] == '1');
+    if (const char *e = getenv("FUZZYHIP_FUSED_MIN_MB")) c->fused_min_bytes = (uint64_t)std::max(0, atoi(e)) << 20;
+    if (const char *e = getenv("FUZZYHIP_SLAB_KB")) c->slab_bytes = (uint64_t)std::max(1, atoi(e)) << 10;
     if (const char *e = getenv("FUZZYHIP_STREAM_WAVES")) c->stream_waves = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("FUZZYHIP_STREAM_BLOCKS")) c->stream_blocks = (uint32_t)std::max(1, atoi(e));
     {
@@ -656,7 +710,7 @@ static int fz_corpus_save_impl(fz_corpus *c, const char *path)
             if (v.sym_of_cp[cp]) { alpha.push_back(cp); alpha.push_back(v.sym_of_cp[cp]); }
         const uint64_t vh[16] = {v.wide, v.npad, v.ntiles, v.max_ndw, v.max_len, v.max_tok, v.alphabet,
                                  v.total_symbols, v.total_tokens, v.n_sym_words, v.n_tok_slots,
-                                 v.n_s1, v.n_s2, v.n_slow, (uint64_t)alpha.size(), 0};
+                                 v.n_s1, v.n_s2, v.n_slow, (uint64_t)alpha.size(), v.n_sample_tiles};
         ok = ok && put(f, vh, 16) && put(f, alpha.data(), alpha.size());
         if (!ok) break;
         if ((rc = dump_device(f, v.d_sym, v.n_sym_words)) != FZ_OK) break;
@@ -738,6 +792,8 @@ static int fz_corpus_load_impl(const char *path, int device, uint64_t base_index
         v.max_len = (uint32_t)vh[4]; v.max_tok = (uint32_t)vh[5]; v.alphabet = (uint32_t)vh[6];
         v.total_symbols = vh[7]; v.total_tokens = vh[8]; v.n_sym_words = vh[9]; v.n_tok_slots = vh[10];
         v.n_s1 = (uint32_t)vh[11]; v.n_s2 = (uint32_t)vh[12]; v.n_slow = (uint32_t)vh[13];
+        v.n_sample_tiles = (uint32_t)vh[15];             // 0 (files of the first format revision): no sample in front
+        if (vh[15] > vh[2]) return bad("inconsistent view header");
         if (v.npad != (uint32_t)((c->n + FZ_TILE - 1) / FZ_TILE) * FZ_TILE || v.ntiles != v.npad / FZ_TILE ||
             v.alphabet > 0x10000u || v.n_sym_words > 0xFFFFFFFFull || v.n_tok_slots > 0xFFFFFFFFull ||
             vh[14] > 2ull * 0x110000ull || (vh[14] & 1ull))
@@ -1125,24 +1181,37 @@ static int scorer_plan(int scorer, int *view, int *mode, FzTies *ties)
     }
 }
 
-// Scores `rows` queries (q0 .. q0+rows) of one view into the workspace score matrix, rows [0, rows): builds the
-// query tables on the host, uploads them, launches the scoring kernels on `st`.  `ev_begin`, when
-// given, is recorded between the upload and the first launch.
-static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const uint32_t *q_cps,
-                      const uint64_t *q_offs, uint64_t q0, uint32_t rows, uint64_t row_stride,
-                      hipStream_t st, hipEvent_t ev_begin)
+// ---------------------------------------------------------------------------------------------
+// scoring a chunk of queries: prepare (host tables + upload) and launch (per phase)
+// ---------------------------------------------------------------------------------------------
+// PH_ALL scores every tile into the score matrix.  A fused top-k call (FzEmit, fz_common.h) scores the
+// SAMPLE tiles into a small matrix first (PH_SAMPLE) and the other tiles without one (PH_REST).
+enum Phase { PH_ALL = 0, PH_SAMPLE = 1, PH_REST = 2 };
+
+struct Prepared {
+    QueryBatch b;
+    struct Launch { int W; uint32_t first, count; bool slow_only; };
+    std::vector<FzQuery> qlist;
+    std::vector<Launch> launches;
+    size_t o_q = 0, o_peq = 0, o_id = 0, o_pos = 0, o_len = 0, o_rec = 0, o_qrec = 0, o_rows = 0;
+};
+
+// Builds the query tables of `rows` queries (q0 .. q0+rows; query r of the chunk writes score row r) on
+// the host and uploads them as one blob on `st`.
+static int prepare_rows(fz_corpus *c, int view_kind, int kmode, const uint32_t *q_cps, const uint64_t *q_offs,
+                        uint64_t q0, uint32_t rows, hipStream_t st, Prepared &P)
 {
     const View &v = c->views[view_kind];
     int rc;
     std::vector<Tok> toks;
     auto t0 = std::chrono::steady_clock::now();
-    QueryBatch b;
+    QueryBatch &b = P.b;
     const bool stream_mode = kmode == FZ_MODE_TOKEN_SET || kmode == FZ_MODE_RATIO;
-    b.allow_stream = c->use_stream && stream_mode && (v.n_s0 + v.n_s1 + v.n_s2) > 0 && row_stride <= 0xFFFFFFFFull;
+    b.allow_stream = c->use_stream && stream_mode && (v.n_s0 + v.n_s1 + v.n_s2) > 0;
     // the score table covers L < 128; a stream tile holds at most 64 symbols.  token_set looks up
     // L = m + clen - 2, ratio L = m + clen.
     b.stream_max_m = kmode == FZ_MODE_TOKEN_SET ? (FZ_STREAM_TAB + 1u - 64u) : (FZ_STREAM_TAB - 1u - 64u);
-    if (b.allow_stream) { b.recs.reserve((size_t)rows * 6 + 2); b.qrec.reserve(rows); }
+    if (b.allow_stream) { b.recs.reserve((size_t)rows * 6 + 8); b.qrec.reserve(rows); }
     for (uint32_t r = 0; r < rows; ++r) {
         const uint64_t qi = q0 + r;
         if (q_offs[qi + 1] < q_offs[qi]) return fail(FZ_ERR_INVALID, "query offsets not monotone at %llu", (unsigned long long)qi);
@@ -1150,24 +1219,21 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
         if (rc != FZ_OK) return rc;
     }
     const auto t_prep = std::chrono::steady_clock::now();
-    for (int i = 0; i < 8; ++i) b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches a few records ahead
+    for (int i = 0; i < 8; ++i) b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches records ahead
     // one device blob: [FzQuery list][peq][tok_id][tok_pos][tok_len1][stream records][qrec][rows]
-    struct Launch { int W; uint32_t first, count; bool slow_only; };
-    std::vector<FzQuery> qlist;
-    std::vector<Launch> launches;
     for (int pass = 0; pass < 2; ++pass)
         for (auto &kv : (pass == 0 ? b.classes : b.slow_classes)) {
-            launches.push_back({kv.first, (uint32_t)qlist.size(), (uint32_t)kv.second.size(), pass == 1});
-            qlist.insert(qlist.end(), kv.second.begin(), kv.second.end());
+            P.launches.push_back({kv.first, (uint32_t)P.qlist.size(), (uint32_t)kv.second.size(), pass == 1});
+            P.qlist.insert(P.qlist.end(), kv.second.begin(), kv.second.end());
         }
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t o_q = 0, o_peq = align16(o_q + qlist.size() * sizeof(FzQuery));
-    const size_t o_id = o_peq + b.peq.size() * 4, o_pos = o_id + b.tok_id.size() * 4;
-    const size_t o_len = o_pos + b.tok_pos.size() * 4;
-    const size_t o_rec = align16(o_len + b.tok_len1.size() * 4);
-    const size_t o_qrec = o_rec + b.recs.size() * sizeof(FzRec);
-    const size_t o_rows = align16(o_qrec + b.qrec.size() * 4);
-    const size_t total = o_rows + 256;
+    P.o_q = 0; P.o_peq = align16(P.o_q + P.qlist.size() * sizeof(FzQuery));
+    P.o_id = P.o_peq + b.peq.size() * 4; P.o_pos = P.o_id + b.tok_id.size() * 4;
+    P.o_len = P.o_pos + b.tok_pos.size() * 4;
+    P.o_rec = align16(P.o_len + b.tok_len1.size() * 4);
+    P.o_qrec = P.o_rec + b.recs.size() * sizeof(FzRec);
+    P.o_rows = align16(P.o_qrec + b.qrec.size() * 4);
+    const size_t total = P.o_rows + 256;
     // The blob is assembled in pinned host memory and copied without a stream synchronisation: two
     // buffers take turns, and one is rewritten only after the copy that last read it has completed (its
     // event), so the host builds the tables of the next chunk while the GPU works on this one.
@@ -1176,16 +1242,16 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
     HIP_TRY(hipEventSynchronize(c->ev_blob[bi]));
     if ((rc = ensure_pinned(w, &c->h_blob[bi], &c->h_blob_cap[bi], total, "query tables")) != FZ_OK) return rc;
     uint8_t *blob = c->h_blob[bi];
-    if (!qlist.empty()) memcpy(blob + o_q, qlist.data(), qlist.size() * sizeof(FzQuery));
-    if (!b.peq.empty()) memcpy(blob + o_peq, b.peq.data(), b.peq.size() * 4);
+    if (!P.qlist.empty()) memcpy(blob + P.o_q, P.qlist.data(), P.qlist.size() * sizeof(FzQuery));
+    if (!b.peq.empty()) memcpy(blob + P.o_peq, b.peq.data(), b.peq.size() * 4);
     if (!b.tok_id.empty()) {
-        memcpy(blob + o_id, b.tok_id.data(), b.tok_id.size() * 4);
-        memcpy(blob + o_pos, b.tok_pos.data(), b.tok_pos.size() * 4);
-        memcpy(blob + o_len, b.tok_len1.data(), b.tok_len1.size() * 4);
+        memcpy(blob + P.o_id, b.tok_id.data(), b.tok_id.size() * 4);
+        memcpy(blob + P.o_pos, b.tok_pos.data(), b.tok_pos.size() * 4);
+        memcpy(blob + P.o_len, b.tok_len1.data(), b.tok_len1.size() * 4);
     }
-    memcpy(blob + o_rec, b.recs.data(), b.recs.size() * sizeof(FzRec));
-    if (!b.qrec.empty()) memcpy(blob + o_qrec, b.qrec.data(), b.qrec.size() * 4);
-    memcpy(blob + o_rows, b.row_of_sym, 256);
+    memcpy(blob + P.o_rec, b.recs.data(), b.recs.size() * sizeof(FzRec));
+    if (!b.qrec.empty()) memcpy(blob + P.o_qrec, b.qrec.data(), b.qrec.size() * 4);
+    memcpy(blob + P.o_rows, b.row_of_sym, 256);
     c->timing.host_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if ((rc = ensure(w, &w.d_qbuf, &w.qbuf_cap, total, "query tables")) != FZ_OK) return rc;
     HIP_TRY(hipMemcpyAsync(w.d_qbuf, blob, total, hipMemcpyHostToDevice, st));
@@ -1193,21 +1259,42 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
     if (getenv("FUZZYHIP_PREP_DEBUG"))
         fprintf(stderr, "[prep dbg] %u queries: tables %.3f ms, tables + blob %.3f ms (%zu bytes)\n", rows,
                 std::chrono::duration<double, std::milli>(t_prep - t0).count(), c->timing.host_prep_ms, total);
+    return FZ_OK;
+}
 
-    if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, st));
-    for (auto &l : launches) {
+// Launches the scoring kernels of a prepared chunk over the tiles of `ph`.  Scores go to
+// d_scores[row][row_stride] (physical position = tile * 64 + lane), or, with `emit`, keys that reach the
+// row's limit are appended to its list.
+static int launch_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const Prepared &P, Phase ph,
+                       uint8_t *d_scores, uint64_t row_stride, const FzEmit *emit, hipStream_t st)
+{
+    const View &v = c->views[view_kind];
+    const Workspace &w = *c->ws;
+    const QueryBatch &b = P.b;
+    auto range = [&](const uint32_t *list, uint32_t n_sample, uint32_t n_total, const uint32_t **out_list, uint32_t *out_n) {
+        if (ph == PH_ALL) { *out_list = list; *out_n = n_total; }
+        else if (ph == PH_SAMPLE) { *out_list = list; *out_n = n_sample; }
+        else { *out_list = list + n_sample; *out_n = n_total - n_sample; }
+    };
+    for (auto &l : P.launches) {
         const int W = l.W;
         const uint32_t first = l.first, count = l.count;
         FzScoreParams p{};
         p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
-        p.ntiles = l.slow_only ? v.n_slow : v.ntiles;
-        p.tile_list = l.slow_only ? v.d_tiles_slow : nullptr;
+        if (l.slow_only) {
+            range(v.d_tiles_slow, v.ns_slow, v.n_slow, &p.tile_list, &p.ntiles);
+        } else {                                            // every tile of the phase: a contiguous physical range
+            p.tile_list = nullptr;
+            p.tile_base = ph == PH_REST ? v.n_sample_tiles : 0u;
+            p.ntiles = ph == PH_ALL ? v.ntiles : (ph == PH_SAMPLE ? v.n_sample_tiles : v.ntiles - v.n_sample_tiles);
+        }
+        if (p.ntiles == 0) continue;
         p.alphabet = v.alphabet;
         p.wide = v.wide ? 1u : 0u;
         uint32_t pmax = 1, peq_rows = 1;
         for (uint32_t i = 0; i < count; ++i) {
-            pmax = std::max(pmax, qlist[first + i].n_ids);
-            peq_rows = std::max(peq_rows, qlist[first + i].peq_rows);
+            pmax = std::max(pmax, P.qlist[first + i].n_ids);
+            peq_rows = std::max(peq_rows, P.qlist[first + i].peq_rows);
         }
         p.pmax = pmax;
         p.peq_rows = peq_rows;
@@ -1221,41 +1308,48 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
         uint32_t tpb = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(p.nwaves, work / 8192));
         tpb = (tpb + p.nwaves - 1) / p.nwaves * p.nwaves;
         p.tiles_per_block = tpb;
-        p.queries = reinterpret_cast<const FzQuery *>(w.d_qbuf + o_q) + first;
-        p.qblob = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_peq);
-        p.qtok_id = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_id);
-        p.qtok_pos = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_pos);
-        p.qtok_len1 = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_len);
-        p.scores = w.d_scores; p.row_stride = row_stride;
+        p.queries = reinterpret_cast<const FzQuery *>(w.d_qbuf + P.o_q) + first;
+        p.qblob = reinterpret_cast<const uint32_t *>(w.d_qbuf + P.o_peq);
+        p.qtok_id = reinterpret_cast<const uint32_t *>(w.d_qbuf + P.o_id);
+        p.qtok_pos = reinterpret_cast<const uint32_t *>(w.d_qbuf + P.o_pos);
+        p.qtok_len1 = reinterpret_cast<const uint32_t *>(w.d_qbuf + P.o_len);
+        p.scores = d_scores; p.row_stride = row_stride;
         p.ties = ties;
+        if (emit) p.emit = *emit;
         HIP_TRY(fz_launch_score(W, kmode, p, count, st));
         c->timing.score_launches++;
     }
     if (!b.qrec.empty()) {
         // odd strides keep the 64 lane columns on distinct banks; the smallest one that holds the rows of
-        // this launch leaves room for the most waves (37: a-z, 0-9 and one spare)
+        // this launch leaves room for the most waves (37: the zero row, a-z and 0-9)
         const uint32_t stride = b.nrows <= 37u ? 37u : (b.nrows <= 41u ? 41u : 65u);
+        const uint32_t *lists[3]; uint32_t counts[3];
+        range(v.d_tiles_s0, v.ns_s0, v.n_s0, &lists[0], &counts[0]);
+        range(v.d_tiles_s1, v.ns_s1, v.n_s1, &lists[1], &counts[1]);
+        range(v.d_tiles_s2, v.ns_s2, v.n_s2, &lists[2], &counts[2]);
         // The (up to) three stream kernels write disjoint columns of the score matrix and each ends in a
         // tail where CUs that have drained their queue idle: they go to three streams, forked after the
         // upload and joined before anything reads the scores, so that one kernel's blocks start on the CUs
         // another one's tail frees.
-        const bool side_by_side = c->overlap && ((v.n_s0 != 0) + (v.n_s1 != 0) + (v.n_s2 != 0)) > 1;
+        const bool side_by_side = c->overlap && ((counts[0] != 0) + (counts[1] != 0) + (counts[2] != 0)) > 1;
         if (side_by_side) {
             HIP_TRY(hipEventRecord(c->ev_fork, st));
             for (hipStream_t a : c->aux_stream) HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
         }
+        // bytes of symbols, token ids and token ends one tile brings into the caches
+        const uint64_t tile_bytes = std::max<uint64_t>(1, (v.n_sym_words * 4ull + v.n_tok_slots * 6ull) / std::max<uint32_t>(1, v.ntiles));
         int n_aux = 0, n_launched = 0;
         bool used_aux[2] = {false, false};
         for (int cls = 0; cls <= 2; ++cls) {           // 0: packed pairs of short tiles, 1 / 2: pattern words
             const int W = cls == 2 ? 2 : 1;
-            const uint32_t nt = cls == 0 ? v.n_s0 : (cls == 1 ? v.n_s1 : v.n_s2);
+            const uint32_t nt = counts[cls];
             if (nt == 0) continue;
             hipStream_t lst = st;                      // the first kernel stays on the caller's stream
             if (side_by_side && n_launched > 0) { lst = c->aux_stream[n_aux]; used_aux[n_aux] = true; ++n_aux; }
             const uint32_t units = cls == 0 ? nt / 2u : nt;             // tiles (or tile pairs) to hand out
             FzStreamParams p{};
             p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
-            p.tile_list = cls == 0 ? v.d_tiles_s0 : (cls == 1 ? v.d_tiles_s1 : v.d_tiles_s2);
+            p.tile_list = lists[cls];
             p.ntiles = nt; p.stride = stride;
             p.nwaves = 16;
             while (p.nwaves > 1 && fz_stream_lds_bytes(W, (int)stride, p.nwaves) > 160 * 1024) --p.nwaves;
@@ -1268,6 +1362,8 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
             const uint64_t groups = (p.nq + p.q_per_block - 1) / p.q_per_block;
             if ((uint64_t)units * groups > 0xFFFFFF00ull) return fail(FZ_ERR_LIMIT, "too many work items in one launch");
             p.nitems = (uint32_t)((uint64_t)units * groups);
+            // slabs: every query group passes over one cache-sized run of units before the next run is touched
+            p.slab_units = (uint32_t)std::min<uint64_t>(units, std::max<uint64_t>(1, c->slab_bytes / (tile_bytes * (cls == 0 ? 2u : 1u))));
             // as many persistent blocks as fit the chip at this LDS size; each drains the work queue
             const size_t lds_b = fz_stream_lds_bytes(W, (int)stride, p.nwaves);
             p.grid_blocks = c->n_cus * (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_b) * c->stream_oversub;
@@ -1277,11 +1373,12 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
             p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1u, 32u / p.q_per_block), p.nitems / waves_total));
             p.work_counter = w.d_counters + (size_t)(c->counter_next++ % FZ_COUNTER_SLOTS) * FZ_STREAM_QUEUES * FZ_STREAM_QPAD;
             HIP_TRY(hipMemsetAsync(p.work_counter, 0, FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), lst));
-            p.row_of_sym = w.d_qbuf + o_rows;
-            p.recs = reinterpret_cast<const FzRec *>(w.d_qbuf + o_rec);
-            p.qrec = reinterpret_cast<const uint32_t *>(w.d_qbuf + o_qrec);
+            p.row_of_sym = w.d_qbuf + P.o_rows;
+            p.recs = reinterpret_cast<const FzRec *>(w.d_qbuf + P.o_rec);
+            p.qrec = reinterpret_cast<const uint32_t *>(w.d_qbuf + P.o_qrec);
             p.score_tab = c->d_score_tab[kmode == FZ_MODE_TOKEN_SET ? 0 : 1];
-            p.scores = w.d_scores; p.row_stride = (uint32_t)row_stride;
+            p.scores = d_scores; p.row_stride = (uint32_t)row_stride;
+            if (emit) p.emit = *emit;
             if (cls == 0) HIP_TRY(fz_launch_stream_pk(kmode, p, lst));
             else HIP_TRY(fz_launch_stream(W, kmode, p, lst));
             c->timing.score_launches++;
@@ -1292,6 +1389,203 @@ static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const
                 HIP_TRY(hipEventRecord(c->ev_join[i], c->aux_stream[i]));
                 HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
             }
+    }
+    return FZ_OK;
+}
+
+// prepare + launch over every tile into the workspace score matrix (the two-corpus path)
+static int score_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, const uint32_t *q_cps,
+                      const uint64_t *q_offs, uint64_t q0, uint32_t rows, uint64_t row_stride, hipStream_t st)
+{
+    Prepared P;
+    int rc = prepare_rows(c, view_kind, kmode, q_cps, q_offs, q0, rows, st, P);
+    if (rc != FZ_OK) return rc;
+    return launch_rows(c, view_kind, kmode, ties, P, PH_ALL, c->ws->d_scores, row_stride, nullptr, st);
+}
+
+// Events of one call, for the kernel timings.  A fixed workspace creates nothing, events included: it
+// cycles through the eight made at corpus creation (only its last chunk's kernel times are then reported).
+struct CallEvents {
+    fz_corpus *c; bool fixed; size_t next = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> score, select;
+    hipEvent_t take()
+    {
+        if (fixed && next >= c->events.size()) { next = 1; score.clear(); select.clear(); }
+        return get_event(c, next++);
+    }
+    int mark(hipEvent_t *out, hipStream_t st)
+    {
+        *out = take();
+        if (!*out) return fail(FZ_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(*out, st));
+        return FZ_OK;
+    }
+};
+
+struct TopkTarget { uint64_t *d_keys; uint32_t *d_cnt; int32_t min_score; uint32_t k; uint32_t flat; };
+
+// Rows [qa, qb) through the score matrix: score every tile, then (top-k) fz_select_topk per row, or copy
+// the rows back in original candidate order.
+static int run_matrix(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint64_t qa, uint64_t qb,
+                      int view_kind, int kmode, FzTies ties, RunMode mode, RunOut &o, const TopkTarget &t,
+                      CallEvents &ev, hipStream_t st)
+{
+    const View &v = c->views[view_kind];
+    Workspace &w = *c->ws;
+    const bool topk = mode == RUN_TOPK_HOST || mode == RUN_TOPK_DEVICE;
+    const uint64_t nq = qb - qa;
+    int rc;
+    const size_t esz = (mode == RUN_DIST_ALL) ? 2 : 1;            // bytes per (query, candidate) result
+    const uint64_t row_stride = v.npad;                            // in elements
+    // *_ALL modes return rows in ORIGINAL candidate order: a second, n-wide copy of each row is made on the device
+    const uint64_t row_bytes = (row_stride + (topk ? 0 : c->n)) * esz;
+    uint64_t rows_per_chunk = std::max<uint64_t>(1, c->ws_limit / row_bytes);
+    rows_per_chunk = std::min<uint64_t>(rows_per_chunk, nq);
+    // Large top-k batches go in `pipe_chunks` pieces: launches are asynchronous, so the host builds the
+    // query tables of piece i+1 while the GPU scores piece i.
+    if (topk && c->pipe_chunks > 1 && nq >= 256u * c->pipe_chunks)
+        rows_per_chunk = std::min<uint64_t>(rows_per_chunk, (nq + c->pipe_chunks - 1) / c->pipe_chunks);
+    // a fixed workspace is never grown: the batch goes in as many chunks as its score rows need
+    if (w.fixed) rows_per_chunk = std::min<uint64_t>(rows_per_chunk, w.scores_cap / row_bytes);
+    if (rows_per_chunk == 0) rows_per_chunk = 1;                    // ensure() below reports the shortfall
+    if ((rc = ensure(w, &w.d_scores, &w.scores_cap, (size_t)(rows_per_chunk * row_bytes), "score matrix")) != FZ_OK) return rc;
+    uint8_t *d_orig_rows = w.d_scores + rows_per_chunk * row_stride * esz;   // [rows][n] in original order (*_ALL modes)
+
+    for (uint64_t q0 = qa; q0 < qb; q0 += rows_per_chunk) {
+        const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, qb - q0);
+        Prepared P;
+        if ((rc = prepare_rows(c, view_kind, kmode, q_cps, q_offs, q0, rows, st, P)) != FZ_OK) return rc;
+        hipEvent_t e0, e1, e2;
+        if ((rc = ev.mark(&e0, st)) != FZ_OK) return rc;
+        if ((rc = launch_rows(c, view_kind, kmode, ties, P, PH_ALL, w.d_scores, row_stride, nullptr, st)) != FZ_OK) return rc;
+        if ((rc = ev.mark(&e1, st)) != FZ_OK) return rc;
+        ev.score.push_back({e0, e1});
+        c->timing.pairs += (uint64_t)rows * c->n;
+
+        if (topk) {
+            FzSelectParams sp{};
+            sp.scores = w.d_scores; sp.row_stride = row_stride; sp.n = (uint32_t)c->n; sp.n_orig = (uint32_t)c->n;
+            sp.orig_of_phys = v.d_orig_of_phys; sp.phys_of_orig = v.d_phys_of_orig;
+            sp.min_score = t.min_score; sp.k = t.k; sp.base_index = c->base;
+            sp.out_keys = t.d_keys + q0 * t.k; sp.out_cnt = t.d_cnt ? t.d_cnt + q0 : nullptr;
+            sp.flat = t.flat;
+            struct DevFree { void operator()(uint64_t *p) const { if (p) (void)hipFree(p); } };
+            std::unique_ptr<uint64_t, DevFree> dbg_holder;       // freed on the early returns below too
+            uint64_t *d_dbg = nullptr;
+            if (!w.fixed && getenv("FUZZYHIP_SELECT_DEBUG")) {
+                HIP_TRY(hipMalloc((void **)&d_dbg, (size_t)rows * 64));
+                dbg_holder.reset(d_dbg);
+                HIP_TRY(hipMemsetAsync(d_dbg, 0, (size_t)rows * 64, st));
+                sp.dbg = d_dbg;
+            }
+            HIP_TRY(fz_launch_select(sp, rows, st));
+            if (d_dbg) {      // diagnostics only: phase times of the slowest rows (100 MHz wall clock)
+                std::vector<uint64_t> h((size_t)rows * 8);
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+                dbg_holder.reset();
+                uint32_t worst = 0;
+                for (uint32_t r = 0; r < rows; ++r) if (h[r * 8 + 4] - h[r * 8] > h[worst * 8 + 4] - h[worst * 8]) worst = r;
+                const uint64_t *x = &h[(size_t)worst * 8];
+                fprintf(stderr, "[select dbg] slowest row %u: passA %.1f us, passB %.1f us, ties %.1f us, sort %.1f us; c_eq %llu need %llu sstar %llu\n",
+                        worst, (x[1] - x[0]) / 100.0, (x[2] - x[1]) / 100.0, (x[3] - x[2]) / 100.0, (x[4] - x[3]) / 100.0,
+                        (unsigned long long)x[5], (unsigned long long)x[6], (unsigned long long)x[7]);
+            }
+            c->timing.select_launches++;
+            if ((rc = ev.mark(&e2, st)) != FZ_OK) return rc;
+            ev.select.push_back({e1, e2});
+        } else {
+            // physical -> original order on the device (a gather through phys_of_orig), then one contiguous
+            // copy straight into the caller's rows: no host-side permutation
+            HIP_TRY(fz_launch_unpermute(w.d_scores, row_stride, d_orig_rows, c->n, v.d_phys_of_orig, (uint32_t)c->n, rows, (uint32_t)esz, st));
+            uint8_t *dst = esz == 1 ? o.scores + (q0 * c->n) : reinterpret_cast<uint8_t *>(o.dists + q0 * c->n);
+            HIP_TRY(hipMemcpyAsync(dst, d_orig_rows, (size_t)rows * c->n * esz, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+    return FZ_OK;
+}
+
+// Fused threshold + top-k (FzEmit, fz_common.h): sample tiles -> small score matrix -> fz_select_topk fixes
+// each row's limit -> the other tiles append the keys that reach it -> fz_merge_lists.  No score matrix
+// over the whole shard, so a batch is not cut to fit one.  A chunk whose lists overflowed is redone
+// through run_matrix at the end (results identical either way).
+static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                     int view_kind, int kmode, FzTies ties, const TopkTarget &t, RunMode mode, RunOut &o,
+                     CallEvents &ev, hipStream_t st)
+{
+    const View &v = c->views[view_kind];
+    Workspace &w = *c->ws;
+    int rc;
+    const uint64_t ns_pad = (uint64_t)v.n_sample_tiles * FZ_TILE;
+    const uint32_t cap = FZ_EMIT_CAP;
+    auto a256 = [](uint64_t x) { return (x + 255ull) & ~255ull; };
+    // arena (the workspace's score buffer): [overflow counters][per chunk: limits | counts | lists | sample scores]
+    const uint64_t ovf_bytes = a256((uint64_t)FZ_FUSED_MAX_CHUNKS * 4);
+    const uint64_t per_row = ns_pad + (uint64_t)cap * 8 + 8 + 4;
+    const uint64_t budget = w.fixed ? w.scores_cap : std::max<uint64_t>(c->ws_limit, ovf_bytes + per_row + 1024);
+    if (budget < ovf_bytes + per_row + 1024)
+        return fail(FZ_ERR_LIMIT, "fz_query_topk_noalloc: one row of this corpus needs %llu bytes of the static scratch buffer, %llu are left",
+                    (unsigned long long)(per_row + 1024), (unsigned long long)(budget > ovf_bytes ? budget - ovf_bytes : 0));
+    uint64_t rows_per_chunk = std::min<uint64_t>(nq, (budget - ovf_bytes - 1024) / per_row);
+    if (c->pipe_chunks > 1 && nq >= 256u * c->pipe_chunks)
+        rows_per_chunk = std::min<uint64_t>(rows_per_chunk, (nq + c->pipe_chunks - 1) / c->pipe_chunks);
+    rows_per_chunk = std::max<uint64_t>(rows_per_chunk, (nq + FZ_FUSED_MAX_CHUNKS - 1) / FZ_FUSED_MAX_CHUNKS);
+    const uint64_t o_lim = ovf_bytes, o_cnt = o_lim + a256(rows_per_chunk * 8), o_list = o_cnt + a256(rows_per_chunk * 4);
+    const uint64_t o_sc = o_list + a256(rows_per_chunk * cap * 8);
+    const uint64_t arena = o_sc + a256(rows_per_chunk * ns_pad);
+    if ((rc = ensure(w, &w.d_scores, &w.scores_cap, (size_t)arena, "fused top-k workspace")) != FZ_OK) return rc;
+    uint32_t *d_ovf = reinterpret_cast<uint32_t *>(w.d_scores);
+    uint64_t *d_lim = reinterpret_cast<uint64_t *>(w.d_scores + o_lim);
+    uint32_t *d_ecnt = reinterpret_cast<uint32_t *>(w.d_scores + o_cnt);
+    uint64_t *d_list = reinterpret_cast<uint64_t *>(w.d_scores + o_list);
+    uint8_t *d_sc = w.d_scores + o_sc;
+    const uint32_t nchunks = (uint32_t)((nq + rows_per_chunk - 1) / rows_per_chunk);
+    HIP_TRY(hipMemsetAsync(d_ovf, 0, (size_t)nchunks * 4, st));
+
+    uint32_t ci = 0;
+    for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk, ++ci) {
+        const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, nq - q0);
+        Prepared P;
+        if ((rc = prepare_rows(c, view_kind, kmode, q_cps, q_offs, q0, rows, st, P)) != FZ_OK) return rc;
+        hipEvent_t e0, e1, e2, e3, e4;
+        if ((rc = ev.mark(&e0, st)) != FZ_OK) return rc;
+        if ((rc = launch_rows(c, view_kind, kmode, ties, P, PH_SAMPLE, d_sc, ns_pad, nullptr, st)) != FZ_OK) return rc;
+        if ((rc = ev.mark(&e1, st)) != FZ_OK) return rc;
+        FzSelectParams sp{};
+        sp.scores = d_sc; sp.row_stride = ns_pad; sp.n = (uint32_t)ns_pad; sp.n_orig = (uint32_t)c->n;
+        sp.orig_of_phys = v.d_orig_of_phys; sp.phys_of_orig = v.d_phys_of_orig;
+        sp.min_score = t.min_score; sp.k = t.k; sp.base_index = c->base;
+        sp.out_keys = t.d_keys + q0 * t.k; sp.out_cnt = nullptr; sp.flat = 0; sp.out_lim = d_lim; sp.walk = v.d_sample_walk;
+        HIP_TRY(fz_launch_select(sp, rows, st));
+        HIP_TRY(hipMemsetAsync(d_ecnt, 0, (size_t)rows * 4, st));
+        if ((rc = ev.mark(&e2, st)) != FZ_OK) return rc;
+        FzEmit em{};
+        em.lim = d_lim; em.list = d_list; em.cnt = d_ecnt; em.cap = cap;
+        em.orig_of_phys = v.d_orig_of_phys; em.base_index = c->base;
+        if ((rc = launch_rows(c, view_kind, kmode, ties, P, PH_REST, nullptr, 0, &em, st)) != FZ_OK) return rc;
+        if ((rc = ev.mark(&e3, st)) != FZ_OK) return rc;
+        FzMergeParams mp{};
+        mp.sample_keys = t.d_keys + q0 * t.k; mp.list = d_list; mp.cnt = d_ecnt; mp.cap = cap; mp.k = t.k;
+        mp.out_keys = t.d_keys + q0 * t.k; mp.out_cnt = t.d_cnt ? t.d_cnt + q0 : nullptr; mp.overflow = d_ovf + ci;
+        HIP_TRY(fz_launch_merge(mp, rows, st));
+        if ((rc = ev.mark(&e4, st)) != FZ_OK) return rc;
+        ev.score.push_back({e0, e1}); ev.score.push_back({e2, e3});
+        ev.select.push_back({e1, e2}); ev.select.push_back({e3, e4});
+        c->timing.select_launches += 2;
+        c->timing.pairs += (uint64_t)rows * c->n;
+    }
+    // lists that overflowed (an adversarial order of arrival; none in any workload measured): redo those chunks
+    std::vector<uint32_t> h_ovf(nchunks, 0u);
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(h_ovf.data(), d_ovf, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
+    ci = 0;
+    for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk, ++ci) {
+        if (h_ovf[ci] == 0u) continue;
+        if (getenv("FUZZYHIP_TRACE")) fprintf(stderr, "fuzzyhip: %u rows of chunk %u overflowed their lists; chunk redone through the score matrix\n", h_ovf[ci], ci);
+        c->timing.fused_fallback_chunks++;
+        const uint64_t qb = std::min<uint64_t>(nq, q0 + rows_per_chunk);
+        if ((rc = run_matrix(c, q_cps, q_offs, q0, qb, view_kind, kmode, ties, mode, o, t, ev, st)) != FZ_OK) return rc;
     }
     return FZ_OK;
 }
@@ -1345,109 +1639,34 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     }
     if (c->n == 0) return FZ_OK;                                  // *_ALL of an empty corpus
 
-    const size_t esz = (mode == RUN_DIST_ALL) ? 2 : 1;            // bytes per (query, candidate) result
-    const uint64_t row_stride = v.npad;                            // in elements
-    uint64_t rows_per_chunk = std::max<uint64_t>(1, c->ws_limit / (row_stride * esz));
-    rows_per_chunk = std::min<uint64_t>(rows_per_chunk, nq);
-    // Large top-k batches go in `pipe_chunks` pieces: launches are asynchronous, so the host builds the
-    // query tables of piece i+1 while the GPU scores piece i.
-    if (topk && c->pipe_chunks > 1 && nq >= 256u * c->pipe_chunks)
-        rows_per_chunk = std::min<uint64_t>(rows_per_chunk, (nq + c->pipe_chunks - 1) / c->pipe_chunks);
-    // a fixed workspace is never grown: the batch goes in as many chunks as its score rows need
-    if (w.fixed) rows_per_chunk = std::min<uint64_t>(rows_per_chunk, w.scores_cap / (row_stride * esz));
-    if (rows_per_chunk == 0) rows_per_chunk = 1;                    // ensure() below reports the shortfall
-    if ((rc = ensure(w, &w.d_scores, &w.scores_cap, (size_t)(rows_per_chunk * row_stride * esz), "score matrix")) != FZ_OK) return rc;
-
-    std::vector<Tok> toks;
-    std::vector<uint8_t> h_rows;
-    size_t ev = 0;
-    std::vector<std::pair<size_t, size_t>> score_spans, select_spans;
-    hipEvent_t ev_first = get_event(c, ev++), ev_last = nullptr;
-    HIP_TRY(hipEventRecord(ev_first, st));
-
-    for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk) {
-        const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, nq - q0);
-        // a fixed workspace creates nothing, events included: chunks beyond the first reuse the three
-        // events of their predecessor (only the last chunk's kernel times are then reported)
-        if (w.fixed && ev + 3 > c->events.size() - 1) ev = 1;
-        hipEvent_t e0 = get_event(c, ev++), e1 = get_event(c, ev++);
-        if (!e0 || !e1) return fail(FZ_ERR_HIP, "hipEventCreate failed");
-        if (w.fixed) { score_spans.clear(); select_spans.clear(); }
-        if ((rc = score_rows(c, view_kind, kmode, ties, q_cps, q_offs, q0, rows, row_stride, st, e0)) != FZ_OK) return rc;
-        HIP_TRY(hipEventRecord(e1, st));
-        score_spans.push_back({ev - 2, ev - 1});
-        c->timing.pairs += (uint64_t)rows * c->n;
-
-        if (topk) {
-            FzSelectParams sp{};
-            sp.scores = w.d_scores; sp.row_stride = row_stride; sp.n = (uint32_t)c->n;
-            sp.orig_of_phys = v.d_orig_of_phys; sp.phys_of_orig = v.d_phys_of_orig;
-            sp.min_score = min_score; sp.k = k; sp.base_index = c->base;
-            sp.out_keys = d_keys + q0 * k; sp.out_cnt = d_cnt ? d_cnt + q0 : nullptr;
-            sp.flat = o.flat;
-            struct DevFree { void operator()(uint64_t *p) const { if (p) (void)hipFree(p); } };
-            std::unique_ptr<uint64_t, DevFree> dbg_holder;       // freed on the early returns below too
-            uint64_t *d_dbg = nullptr;
-            if (getenv("FUZZYHIP_SELECT_DEBUG")) {
-                HIP_TRY(hipMalloc((void **)&d_dbg, (size_t)rows * 64));
-                dbg_holder.reset(d_dbg);
-                HIP_TRY(hipMemsetAsync(d_dbg, 0, (size_t)rows * 64, st));
-                sp.dbg = d_dbg;
-            }
-            HIP_TRY(fz_launch_select(sp, rows, st));
-            if (d_dbg) {      // diagnostics only: phase times of the slowest rows (100 MHz wall clock)
-                std::vector<uint64_t> h((size_t)rows * 8);
-                HIP_TRY(hipStreamSynchronize(st));
-                HIP_TRY(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
-                dbg_holder.reset();
-                uint32_t worst = 0;
-                for (uint32_t r = 0; r < rows; ++r) if (h[r * 8 + 4] - h[r * 8] > h[worst * 8 + 4] - h[worst * 8]) worst = r;
-                const uint64_t *w = &h[(size_t)worst * 8];
-                fprintf(stderr, "[select dbg] slowest row %u: passA %.1f us, passB %.1f us, ties %.1f us, sort %.1f us; c_eq %llu need %llu sstar %llu\n",
-                        worst, (w[1] - w[0]) / 100.0, (w[2] - w[1]) / 100.0, (w[3] - w[2]) / 100.0, (w[4] - w[3]) / 100.0,
-                        (unsigned long long)w[5], (unsigned long long)w[6], (unsigned long long)w[7]);
-            }
-            c->timing.select_launches++;
-            hipEvent_t e2 = get_event(c, ev++);
-            if (!e2) return fail(FZ_ERR_HIP, "hipEventCreate failed");
-            HIP_TRY(hipEventRecord(e2, st));
-            select_spans.push_back({ev - 2, ev - 1});
-            ev_last = e2;
-        } else {
-            h_rows.resize((size_t)rows * row_stride * esz);
-            HIP_TRY(hipMemcpyAsync(h_rows.data(), w.d_scores, h_rows.size(), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            for (uint32_t r = 0; r < rows; ++r) {
-                if (esz == 1) {
-                    const uint8_t *src = h_rows.data() + (size_t)r * row_stride;
-                    uint8_t *dst = o.scores + (q0 + r) * c->n;
-                    for (uint64_t ph = 0; ph < c->n; ++ph) dst[v.h_orig_of_phys[ph]] = src[ph];
-                } else {
-                    const uint16_t *src = reinterpret_cast<const uint16_t *>(h_rows.data()) + (size_t)r * row_stride;
-                    uint16_t *dst = o.dists + (q0 + r) * c->n;
-                    for (uint64_t ph = 0; ph < c->n; ++ph) dst[v.h_orig_of_phys[ph]] = src[ph];
-                }
-            }
-            ev_last = e1;
-        }
-    }
+    CallEvents ev{c, w.fixed};
+    hipEvent_t ev_first, ev_last;
+    if ((rc = ev.mark(&ev_first, st)) != FZ_OK) return rc;
+    const TopkTarget t{d_keys, d_cnt, min_score, k, o.flat};
+    // fused threshold + top-k when the view keeps a sample in front (large shards), the order is by score,
+    // and k is small enough for the lists; the score matrix otherwise
+    const bool fused = topk && c->use_fused && !o.flat && k <= FZ_FUSED_MAX_K && v.n_sample_tiles < v.ntiles &&
+                       (uint64_t)nq * v.npad >= c->fused_min_bytes && (mode == RUN_TOPK_HOST || o.sync);
+    if (fused && getenv("FUZZYHIP_TRACE")) fprintf(stderr, "fuzzyhip: fused top-k over %u rows (%u of %u tiles sampled)\n", nq, v.n_sample_tiles, v.ntiles);
+    if (fused) rc = run_fused(c, q_cps, q_offs, nq, view_kind, kmode, ties, t, mode, o, ev, st);
+    else rc = run_matrix(c, q_cps, q_offs, 0, nq, view_kind, kmode, ties, mode, o, t, ev, st);
+    if (rc != FZ_OK) return rc;
+    c->timing.fused = fused ? 1u : 0u;
 
     if (mode == RUN_TOPK_HOST) {
         if ((rc = ensure_pinned(w, &c->h_keys, &c->h_keys_cap, (size_t)nq * k * 8, "top-k keys")) != FZ_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_keys, d_keys, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-        hipEvent_t e3 = get_event(c, ev++);
-        if (!e3) return fail(FZ_ERR_HIP, "hipEventCreate failed");
-        HIP_TRY(hipEventRecord(e3, st));
-        ev_last = e3;
+        if ((rc = ev.mark(&ev_last, st)) != FZ_OK) return rc;
         HIP_TRY(hipStreamSynchronize(st));
         decode_keys(c->h_keys, nq, k, o.idx, o.score, o.cnt);
-    } else if (mode == RUN_TOPK_DEVICE) {
-        if (!o.sync) return FZ_OK;                  // timings are not collected on the async path
+    } else {
+        if (mode == RUN_TOPK_DEVICE && !o.sync) return FZ_OK;       // timings are not collected on the async path
+        if ((rc = ev.mark(&ev_last, st)) != FZ_OK) return rc;
         HIP_TRY(hipStreamSynchronize(st));
     }
-    for (auto &s : score_spans) { float ms = 0; if (hipEventElapsedTime(&ms, c->events[s.first], c->events[s.second]) == hipSuccess) c->timing.score_ms += ms; }
-    for (auto &s : select_spans) { float ms = 0; if (hipEventElapsedTime(&ms, c->events[s.first], c->events[s.second]) == hipSuccess) c->timing.select_ms += ms; }
-    if (ev_last) { float ms = 0; if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) c->timing.total_ms = ms; }
+    for (auto &s : ev.score) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.score_ms += ms; }
+    for (auto &s : ev.select) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.select_ms += ms; }
+    { float ms = 0; if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) c->timing.total_ms = ms; }
     return FZ_OK;
 }
 
@@ -1576,8 +1795,8 @@ static int fz_query_topk_pair_impl(fz_corpus *ca, int scorer_a, const uint32_t *
     cb->timing = fz_timing{};
     for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk) {
         const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_per_chunk, nq - q0);
-        if ((rc = score_rows(ca, va, ma, ta, qa_cps, qa_offs, q0, rows, A.npad, st, nullptr)) != FZ_OK) return rc;
-        if ((rc = score_rows(cb, vb, mb, tb, qb_cps, qb_offs, q0, rows, B.npad, st, nullptr)) != FZ_OK) return rc;
+        if ((rc = score_rows(ca, va, ma, ta, qa_cps, qa_offs, q0, rows, A.npad, st)) != FZ_OK) return rc;
+        if ((rc = score_rows(cb, vb, mb, tb, qb_cps, qb_offs, q0, rows, B.npad, st)) != FZ_OK) return rc;
         FzCombineParams cp{};
         cp.scores_a = wa.d_scores; cp.scores_b = wb.d_scores; cp.stride_a = A.npad; cp.stride_b = B.npad;
         cp.phys_a = A.d_phys_of_orig; cp.phys_b = B.d_phys_of_orig; cp.rank_tab = ca->d_rank_tab;

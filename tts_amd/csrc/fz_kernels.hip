@@ -71,6 +71,23 @@ __device__ __forceinline__ uint32_t fz_token_set_score(uint32_t n_qtok, uint32_t
     return r0 > r1 ? r0 : r1;
 }
 
+// Fused threshold + top-k (FzEmit, fz_common.h): every lane of the wave calls this with its score; lanes whose
+// key reaches the row's limit append it to the row's list (one counter add per wave, keys behind it in lane
+// order).  `orig` = 0xFFFFFFFF marks a padding lane.  Wave-uniform control flow only.
+__device__ __forceinline__ void fz_emit(const FzEmit &e, uint32_t row, uint64_t lim, uint32_t sc, uint32_t orig)
+{
+    const uint64_t key = ((uint64_t)sc << FZ_IDX_BITS) | (FZ_IDX_MASK - (e.base_index + (uint64_t)orig));
+    const bool pass = orig != 0xFFFFFFFFu && sc <= 100u && key >= lim;
+    const uint64_t m = __ballot(pass);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u, first = (uint32_t)__builtin_ctzll(m);
+    uint32_t pos = 0u;
+    if (lane == first) pos = atomicAdd(&e.cnt[row], (uint32_t)__popcll(m));
+    pos = (uint32_t)__shfl((int)pos, (int)first, 64);
+    const uint32_t mine = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (pass && mine < e.cap) e.list[(uint64_t)row * e.cap + mine] = key;
+}
+
 // clear bits [s, e) (e > s) of a per-lane bit row stored word-major with stride 64 (row[w*64])
 __device__ __forceinline__ void fz_clear_bits(uint32_t *row, uint32_t s, uint32_t e)
 {
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
     uint32_t t_end = (blockIdx.x + 1u) * p.tiles_per_block;
     if (t_end > p.ntiles) t_end = p.ntiles;
     for (uint32_t tix = blockIdx.x * p.tiles_per_block + wave; tix < t_end; tix += p.nwaves) {
-        const uint32_t tile = p.tile_list ? p.tile_list[tix] : tix;
+        const uint32_t tile = p.tile_list ? p.tile_list[tix] : p.tile_base + tix;
         const FzTile td = p.tiles[tile];
         const uint32_t ntkw = ((uint32_t)td.ndw + SY::TKD - 1u) / SY::TKD;
 
@@ -281,13 +298,15 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
                 reinterpret_cast<uint16_t *>(p.scores)[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint16_t)dist;
             } else {
                 const uint32_t sc = L ? fz_round_ratio(dist, L, p.ties) : 100u;   // two empty strings: 100
-                p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
+                if (p.emit.lim) fz_emit(p.emit, q.out_row, p.emit.lim[q.out_row], sc, p.emit.orig_of_phys[tile * 64u + lane]);
+                else p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
             }
             continue;
         }
 
         const uint32_t sc = fz_token_set_score(q.n_tok, q.m, clen, nhits, sect1, lcs1, p.ties);
-        p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
+        if (p.emit.lim) fz_emit(p.emit, q.out_row, p.emit.lim[q.out_row], sc, p.emit.orig_of_phys[tile * 64u + lane]);
+        else p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
     }
 }
 
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
     uint32_t t_end = (blockIdx.x + 1u) * p.tiles_per_block;
     if (t_end > p.ntiles) t_end = p.ntiles;
     for (uint32_t tix = blockIdx.x * p.tiles_per_block + wave; tix < t_end; tix += p.nwaves) {
-        const uint32_t tile = p.tile_list ? p.tile_list[tix] : tix;
+        const uint32_t tile = p.tile_list ? p.tile_list[tix] : p.tile_base + tix;
         const FzTile td = p.tiles[tile];
         const uint32_t clen = td.ntok ? p.tokend[td.toff + lane] : 0u;   // raw view: one slot = the length
         const uint32_t maxlen = (uint32_t)td.ndw * (uint32_t)SY::SPD;
@@ -439,7 +458,8 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
         uint32_t sc;
         if (!valid) sc = (m == 0u && clen == 0u) ? 100u : 0u;
         else sc = fz_round_ratio(bL - 2u * bl, bL, p.ties);
-        p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
+        if (p.emit.lim) fz_emit(p.emit, q.out_row, p.emit.lim[q.out_row], sc, p.emit.orig_of_phys[tile * 64u + lane]);
+        else p.scores[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = (uint8_t)sc;
     }
 }
 
@@ -564,13 +584,13 @@ __device__ __forceinline__ void fz_stream_step(uint32_t (&V)[W], const uint32_t 
 // tokens: a known token takes its bit off the top of that string and is scanned with an all-zero mask when
 // the bit is set (a token both sides have is in neither difference).  No lane operation depends on the
 // number of symbols: the only scalar branches of a token are its step class and its flags.
-template <int W, int MODE, int STRIDE, int NT>
+template <int W, int MODE, int STRIDE, int NT, bool EMIT>
 __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const FzRec *__restrict__ recs,
                                                   uint8_t *__restrict__ scores, const uint8_t *s_tab,
                                                   uint32_t col_off, const uint32_t (&cid)[FZ_STREAM_MAX_TOK],
                                                   const uint32_t (&Rm)[FZ_STREAM_MAX_TOK][W],
                                                   const uint32_t (&psep)[W], uint32_t clen, uint32_t out_off,
-                                                  uint32_t qgroup)
+                                                  uint32_t orig, uint32_t qgroup)
 {
     constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
@@ -584,6 +604,7 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
         const uint32_t n_ids = (cur.y >> 8) & 0xFFu, nrec = cur.y >> 16;
         const uint32_t id0 = cur.z, id1 = cur.w;
         FZ_ADVANCE();
+        const uint64_t lim = EMIT ? p.emit.lim[out_row] : 0ull;         // scalar load, used at the end of the query
 
         uint32_t M[W], has = 0u;                         // has: bit string "the candidate has query token j"
 #pragma unroll
@@ -686,13 +707,31 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
             const uint32_t L = m + clen;
             sc = s_tab[((L << 6) + ((L - 2u * lcs) >> 1)) & (FZ_STREAM_TAB_BYTES - 1u)];   // T[0][0] = 100: two empty strings
         }
-        uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
-        rowp[out_off] = (uint8_t)sc;
+        if (EMIT) {
+            // fused threshold + top-k: no score matrix; a lane below the limit's score is done here
+            if (__ballot(sc >= (uint32_t)(lim >> FZ_IDX_BITS)) != 0ull) fz_emit(p.emit, out_row, lim, sc, orig);
+        } else {
+            uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
+            rowp[out_off] = (uint8_t)sc;
+        }
     }
 #undef FZ_ADVANCE
 }
 
-template <int W, int MODE, int STRIDE>
+// item -> (query group, unit): items are numbered slab-major.  Slab s holds the units [s*S, min((s+1)*S, units))
+// and its items come group after group: item = s*S*groups + group*size(s) + (unit - s*S).  All scalars.
+__device__ __forceinline__ void fz_item_decode(uint32_t item, uint32_t units, uint32_t S, uint32_t groups,
+                                               uint32_t &qgroup, uint32_t &unit)
+{
+    const uint32_t per_slab = S * groups;
+    const uint32_t slab = item / per_slab, r = item - slab * per_slab;
+    const uint32_t first = slab * S;
+    const uint32_t size = units - first < S ? units - first : S;       // the last slab may be shorter
+    qgroup = r / size;
+    unit = first + (r - qgroup * size);
+}
+
+template <int W, int MODE, int STRIDE, bool EMIT>
 __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const FzRec *__restrict__ recs,
                                                         uint8_t *__restrict__ scores)
 {
@@ -751,7 +790,8 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
         }
         const uint32_t item = queue + pos * FZ_STREAM_QUEUES;
         ++pos;
-        const uint32_t qgroup = item / p.ntiles, tix = item - qgroup * p.ntiles;
+        uint32_t qgroup, tix;
+        fz_item_decode(item, p.ntiles, p.slab_units, (p.nq + p.q_per_block - 1u) / p.q_per_block, qgroup, tix);
         const uint32_t tile = p.tile_list[tix];
         const FzTile td = p.tiles[tile];
         const uint32_t ndw = td.ndw, ntok = td.ntok;
@@ -805,12 +845,13 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
 
         // ---- the queries of this group: a stream of wave-uniform records (scalar loads) ------------
         const uint32_t out_off = tile * 64u + lane;
-        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
-        else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
-        else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, qgroup);
+        const uint32_t orig = EMIT ? p.emit.orig_of_phys[out_off] : 0u;
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
+        else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
+        else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
+        else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
+        else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
+        else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
     }
 }
 
@@ -826,14 +867,14 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
 // of a field beyond its candidate stay 1 in V and in M, so they count neither as matches nor as common
 // tokens.  Everything else is the stream kernel above, with the per-candidate pieces doubled.
 
-template <int MODE, int STRIDE, int NT>
+template <int MODE, int STRIDE, int NT, bool EMIT>
 __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, const FzRec *__restrict__ recs,
                                                      uint8_t *__restrict__ scores, const uint8_t *s_tab,
                                                      uint32_t col_off, const uint32_t (&cid)[2][FZ_PK_MAX_TOK],
                                                      const uint32_t (&Rm)[2][FZ_PK_MAX_TOK], uint32_t psep,
                                                      const uint32_t (&clen)[2], const uint32_t (&out_off)[2],
                                                      const uint32_t (&fmask)[2], const uint32_t (&fw)[2], uint32_t negstop,
-                                                     uint32_t qgroup)
+                                                     const uint32_t (&orig)[2], uint32_t qgroup)
 {
     // Lane constants of the score look-ups (end of the query loop).  With bm = popcount(M & field) and
     // bv = popcount(V & field): sect1 = fw - bm, lcs = fw - bv, and (m + clen) >> 1 = (m >> 1) + (clen >> 1)
@@ -865,6 +906,7 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
         const uint32_t n_ids = (cur.y >> 8) & 0xFFu, nrec = cur.y >> 16;
         const uint32_t id0 = cur.z, id1 = cur.w;
         FZ_ADVANCE();
+        const uint64_t lim = EMIT ? p.emit.lim[out_row] : 0ull;         // scalar load, used at the end of the query
 
         uint32_t M = 0xFFFFFFFFu, has = 0u;
         if (MODE == FZ_MODE_TOKEN_SET && n_ids != 0u) {
@@ -936,8 +978,8 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
 #undef FZ_PK_STEP
         }
 
-        uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
         const uint32_t qs = (m << 6) + (m >> 1), m_odd = 0u - (m & 1u);          // scalars
+        uint32_t sc2[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const uint32_t bv = (uint32_t)__builtin_popcount(V & fm[h]);
@@ -960,13 +1002,25 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
                 // T[L][(L - 2*lcs) >> 1] with L = m + clen
                 sc = fz_tab_load(tab_off, c_tab[h] + both_odd + qs + bv);
             }
-            rowp[out_off[h]] = (uint8_t)sc;
+            sc2[h] = sc;
+        }
+        if (EMIT) {
+            // fused threshold + top-k: no score matrix; lanes below the limit's score are done here
+            const uint32_t ls = (uint32_t)(lim >> FZ_IDX_BITS);
+            if (__ballot((sc2[0] >= ls) | (sc2[1] >= ls)) != 0ull) {
+                fz_emit(p.emit, out_row, lim, sc2[0], orig[0]);
+                fz_emit(p.emit, out_row, lim, sc2[1], orig[1]);
+            }
+        } else {
+            uint8_t *rowp = scores + (uint64_t)out_row * (uint64_t)p.row_stride;     // wave-uniform
+            rowp[out_off[0]] = (uint8_t)sc2[0];
+            rowp[out_off[1]] = (uint8_t)sc2[1];
         }
     }
 #undef FZ_ADVANCE
 }
 
-template <int MODE, int STRIDE>
+template <int MODE, int STRIDE, bool EMIT>
 __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, const FzRec *__restrict__ recs,
                                                            uint8_t *__restrict__ scores)
 {
@@ -1014,7 +1068,8 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
         }
         const uint32_t item = queue + pos * FZ_STREAM_QUEUES;
         ++pos;
-        const uint32_t qgroup = item / npairs, pair = item - qgroup * npairs;
+        uint32_t qgroup, pair;
+        fz_item_decode(item, npairs, p.slab_units, (p.nq + p.q_per_block - 1u) / p.q_per_block, qgroup, pair);
 
         // ---- candidate side: two tiles, once per item --------------------------------------------
         for (uint32_t r = 0; r < (uint32_t)STRIDE; ++r) *reinterpret_cast<uint32_t *>(col + r * 4u) = 0u;
@@ -1068,10 +1123,12 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
             }
         }
         ntok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ntok);
-        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), qgroup);
-        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), qgroup);
-        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), qgroup);
-        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), qgroup);
+        uint32_t orig[2] = {0u, 0u};
+        if (EMIT) { orig[0] = p.emit.orig_of_phys[out_off[0]]; orig[1] = p.emit.orig_of_phys[out_off[1]]; }
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, qgroup);
+        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, qgroup);
+        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, qgroup);
+        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, qgroup);
     }
 }
 
@@ -1080,20 +1137,27 @@ size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves)
     return (size_t)FZ_STREAM_TAB_BYTES + 256u + (size_t)nwaves * W * 64u * stride * 4u;
 }
 
-template <int W, int MODE, int STRIDE>
-static hipError_t launch_stream3(const FzStreamParams &p, hipStream_t st)
+template <int W, int MODE, int STRIDE, bool EMIT>
+static hipError_t launch_stream4(const FzStreamParams &p, hipStream_t st)
 {
     const size_t lds = fz_stream_lds_bytes(W, STRIDE, p.nwaves);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_stream<W, MODE, STRIDE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_stream<W, MODE, STRIDE, EMIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     // persistent blocks (one per CU at full LDS) drain the (query group, tile) work queue
     const uint64_t blocks_needed = ((uint64_t)p.nitems + p.nwaves - 1u) / p.nwaves;
     dim3 grid((uint32_t)(blocks_needed < p.grid_blocks ? blocks_needed : p.grid_blocks));
-    hipLaunchKernelGGL((fz_score_stream<W, MODE, STRIDE>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
+    hipLaunchKernelGGL((fz_score_stream<W, MODE, STRIDE, EMIT>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
     return hipGetLastError();
+}
+
+// EMIT (fused threshold + top-k, FzEmit) is a template flag: the score-matrix build carries no trace of it
+template <int W, int MODE, int STRIDE>
+static hipError_t launch_stream3(const FzStreamParams &p, hipStream_t st)
+{
+    return p.emit.lim ? launch_stream4<W, MODE, STRIDE, true>(p, st) : launch_stream4<W, MODE, STRIDE, false>(p, st);
 }
 
 template <int W, int MODE>
@@ -1105,19 +1169,25 @@ static hipError_t launch_stream2(const FzStreamParams &p, hipStream_t st)
     return hipErrorInvalidValue;
 }
 
-template <int MODE, int STRIDE>
-static hipError_t launch_stream_pk2(const FzStreamParams &p, hipStream_t st)
+template <int MODE, int STRIDE, bool EMIT>
+static hipError_t launch_stream_pk3(const FzStreamParams &p, hipStream_t st)
 {
     const size_t lds = fz_stream_lds_bytes(1, STRIDE, p.nwaves);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_stream_pk<MODE, STRIDE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_stream_pk<MODE, STRIDE, EMIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const uint64_t blocks_needed = ((uint64_t)p.nitems + p.nwaves - 1u) / p.nwaves;
     dim3 grid((uint32_t)(blocks_needed < p.grid_blocks ? blocks_needed : p.grid_blocks));
-    hipLaunchKernelGGL((fz_score_stream_pk<MODE, STRIDE>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
+    hipLaunchKernelGGL((fz_score_stream_pk<MODE, STRIDE, EMIT>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
     return hipGetLastError();
+}
+
+template <int MODE, int STRIDE>
+static hipError_t launch_stream_pk2(const FzStreamParams &p, hipStream_t st)
+{
+    return p.emit.lim ? launch_stream_pk3<MODE, STRIDE, true>(p, st) : launch_stream_pk3<MODE, STRIDE, false>(p, st);
 }
 
 template <int MODE>
@@ -1133,7 +1203,7 @@ static hipError_t launch_stream_pk(const FzStreamParams &p, hipStream_t st)
 hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st)
 {
     if (p.nq == 0u || p.ntiles == 0u) return hipSuccess;
-    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u) return hipErrorInvalidValue;
+    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u || p.slab_units == 0u) return hipErrorInvalidValue;
     if ((p.ntiles & 1u) || (uint64_t)(p.ntiles / 2u) * ((p.nq + p.q_per_block - 1u) / p.q_per_block) != p.nitems) return hipErrorInvalidValue;
     if (mode == FZ_MODE_TOKEN_SET) return launch_stream_pk<FZ_MODE_TOKEN_SET>(p, st);
     if (mode == FZ_MODE_RATIO) return launch_stream_pk<FZ_MODE_RATIO>(p, st);
@@ -1143,7 +1213,7 @@ hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st
 hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_t st)
 {
     if (p.nq == 0u || p.ntiles == 0u) return hipSuccess;
-    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u) return hipErrorInvalidValue;
+    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u || p.slab_units == 0u) return hipErrorInvalidValue;
     if ((uint64_t)p.ntiles * ((p.nq + p.q_per_block - 1u) / p.q_per_block) != p.nitems) return hipErrorInvalidValue;
     if (W == 1 && mode == FZ_MODE_TOKEN_SET) return launch_stream2<1, FZ_MODE_TOKEN_SET>(p, st);
     if (W == 2 && mode == FZ_MODE_TOKEN_SET) return launch_stream2<2, FZ_MODE_TOKEN_SET>(p, st);
@@ -1155,8 +1225,6 @@ hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_
 // ---------------------------------------------------------------------------------------------
 // top-k selection
 // ---------------------------------------------------------------------------------------------
-#define SEL_THREADS 1024u      // fz_select_topk: 16 waves per row
-#define SEL_WAVES (SEL_THREADS / 64u)
 #define SEL16_THREADS 256u     // fz_select16_topk: one thread per histogram bin
 #define SEL_TIECAP 2048u
 #define SEL_PICK_MAX 16u      // up to this many ties are picked by repeated minima instead of a sort
@@ -1237,12 +1305,16 @@ __device__ __forceinline__ void fz_bitonic(T *a, uint32_t P)
     }
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
+// THREADS: 1024 for the row of a whole shard; 256 for short rows (the sample of a fused call), where the
+// block-wide steps (bound updates, tie handling, sorts) dominate and eight rows share a CU instead of two
+// (8 waves per SIMD asked for: at more than 80 SGPRs a CU admits one 1024-thread block instead of two)
+template <uint32_t THREADS>
+__global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
 {
     __shared__ uint32_t s_hist[128];
     __shared__ uint32_t s_cum[129];
-    __shared__ uint64_t s_pick[SEL_WAVES];
-    __shared__ uint32_t s_misc[16 + SEL_WAVES];   // 0: tlow  1: scratch  2: n_gt  3: n_tie  8: count filter  16..: wave counts
+    __shared__ uint64_t s_pick[(THREADS / 64u)];
+    __shared__ uint32_t s_misc[16 + (THREADS / 64u)];   // 0: tlow  1: scratch  2: n_gt  3: n_tie  8: count filter  16..: wave counts
     __shared__ uint64_t s_keys[FZ_MAX_K];
     __shared__ uint32_t s_ties[SEL_TIECAP];
 
@@ -1268,7 +1340,7 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
     // at sstar + 1 as well), so an unmarked vector holds nothing pass B would take.  After the first
     // update of the bound (two iterations) almost no vector is marked.  Rows of more than 64 vectors per
     // thread (> 2^20 candidates) are read in full.
-    const uint32_t per_iter = SEL_THREADS * 16u * SEL_VEC;
+    const uint32_t per_iter = THREADS * 16u * SEL_VEC;
     const uint32_t niter = (n + per_iter - 1u) / per_iter;
     const bool track = niter * SEL_VEC <= 64u;
     uint64_t seen = 0ull;
@@ -1278,12 +1350,12 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
         uint4 v[SEL_VEC];
 #pragma unroll
         for (uint32_t j = 0; j < SEL_VEC; ++j) {
-            const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
+            const uint32_t base = ((it * SEL_VEC + j) * THREADS + tid) * 16u;
             v[j] = base < n ? *reinterpret_cast<const uint4 *>(sc + base) : uint4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (uint32_t j = 0; j < SEL_VEC; ++j) {
-            const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
+            const uint32_t base = ((it * SEL_VEC + j) * THREADS + tid) * 16u;
             const uint32_t wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
             uint32_t any = 0u;
 #pragma unroll
@@ -1323,13 +1395,13 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
             uint4 v[SEL_VEC];
 #pragma unroll
             for (uint32_t j = 0; j < SEL_VEC; ++j) {
-                const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
+                const uint32_t base = ((it * SEL_VEC + j) * THREADS + tid) * 16u;
                 const bool want = !track || ((seen >> (it * SEL_VEC + j)) & 1ull) != 0ull;
                 v[j] = (base < n && want) ? *reinterpret_cast<const uint4 *>(sc + base) : uint4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
             for (uint32_t j = 0; j < SEL_VEC; ++j) {
-                const uint32_t base = ((it * SEL_VEC + j) * SEL_THREADS + tid) * 16u;
+                const uint32_t base = ((it * SEL_VEC + j) * THREADS + tid) * 16u;
                 const uint32_t wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -1379,7 +1451,7 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
                     __syncthreads();
                     if (tid == 0u) {
                         uint64_t m = s_pick[0];
-                        for (uint32_t w = 1; w < SEL_WAVES; ++w) if (s_pick[w] < m) m = s_pick[w];
+                        for (uint32_t w = 1; w < (THREADS / 64u); ++w) if (s_pick[w] < m) m = s_pick[w];
                         const uint32_t pos = (uint32_t)m;
                         s_ties[pos] = s_ties[r];
                         s_ties[r] = (uint32_t)(m >> 32);
@@ -1396,12 +1468,18 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
         } else {
             // many ties: walk candidates in ORIGINAL order and keep the first `need` tied ones
             uint32_t found = 0u;
-            for (uint32_t o0 = 0u; o0 < n && found < need; o0 += SEL_THREADS) {
-                const uint32_t o = o0 + tid;
+            // (a sample row walks the sample's own list of original indices, ascending, not all of the shard's)
+            const uint32_t n_walk = p.walk ? n : p.n_orig;
+            for (uint32_t o0 = 0u; o0 < n_walk && found < need; o0 += THREADS) {
+                const uint32_t wi = o0 + tid;
+                const uint32_t o = wi < n_walk ? (p.walk ? p.walk[wi] : wi) : 0xFFFFFFFFu;
                 bool pred = false;
-                if (o < n) {
-                    const uint32_t s = sc[p.phys_of_orig[o]];
-                    pred = p.flat ? (s >= sstar && s <= 100u) : (s == sstar);    // flat: sstar == min_score
+                if (o < p.n_orig) {
+                    const uint32_t ph = p.phys_of_orig[o];
+                    if (ph < n) {                                                // a row may hold only the front of the physical order
+                        const uint32_t s = sc[ph];
+                        pred = p.flat ? (s >= sstar && s <= 100u) : (s == sstar);    // flat: sstar == min_score
+                    }
                 }
                 const uint64_t bal = __ballot(pred);
                 if (lane == 0u) s_misc[16 + wave] = (uint32_t)__popcll(bal);
@@ -1410,7 +1488,7 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
                 for (uint32_t w = 0; w < wave; ++w) before += s_misc[16 + w];
                 const uint32_t mine = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                 if (pred && mine < need) s_ties[mine] = o;
-                for (uint32_t w = 0; w < SEL_WAVES; ++w) found += s_misc[16 + w];
+                for (uint32_t w = 0; w < (THREADS / 64u); ++w) found += s_misc[16 + w];
                 __syncthreads();
             }
         }
@@ -1438,6 +1516,100 @@ __global__ __launch_bounds__(SEL_THREADS) void fz_select_topk(FzSelectParams p)
         p.out_keys[(uint64_t)row * k + i] = out;
     }
     if (p.out_cnt != nullptr && tid == 0u) p.out_cnt[row] = total;
+    if (p.out_lim != nullptr && tid == 0u) {
+        // what a candidate outside this row must reach to enter the result: beat the k-th key, or, while the
+        // row holds fewer than k, pass the threshold
+        uint64_t lim = (uint64_t)min_score << FZ_IDX_BITS;
+        if (total == k && k != 0u) {
+            const uint64_t key = s_keys[k - 1u];
+            const uint64_t gidx = p.base_index + (uint64_t)(0xFFFFFFFFu - (uint32_t)key);
+            lim = (((key >> 32) << FZ_IDX_BITS) | (FZ_IDX_MASK - gidx)) + 1ull;
+        }
+        p.out_lim[row] = lim;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused top-k, last step: merge the sample's top-k with the keys the other tiles appended
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fz_merge_lists(FzMergeParams p)
+{
+    extern __shared__ __align__(16) uint64_t s_mk[];
+    const uint32_t tid = threadIdx.x, row = blockIdx.x, k = p.k;
+    const uint32_t cnt = p.cnt[row];
+    const uint32_t nl = cnt < p.cap ? cnt : p.cap;
+    if (cnt > p.cap && tid == 0u) atomicAdd(p.overflow, 1u);          // the host redoes the chunk through the score matrix
+    const uint32_t total = k + nl;
+    uint32_t P = 2u;
+    while (P < total) P <<= 1;
+    for (uint32_t i = tid; i < P; i += blockDim.x) {
+        uint64_t v = 0ull;
+        if (i < k) v = p.sample_keys[(uint64_t)row * k + i];
+        else if (i < total) v = p.list[(uint64_t)row * p.cap + (i - k)];
+        s_mk[i] = v;
+    }
+    __syncthreads();
+    fz_bitonic<uint64_t, true>(s_mk, P);
+    uint32_t mine = 0u;
+    for (uint32_t i = tid; i < k; i += blockDim.x) {
+        const uint64_t v = s_mk[i];
+        p.out_keys[(uint64_t)row * k + i] = v;
+        mine += v != 0ull ? 1u : 0u;
+    }
+    if (p.out_cnt != nullptr) {
+        __shared__ uint32_t s_n;
+        if (tid == 0u) s_n = 0u;
+        __syncthreads();
+        if (mine) atomicAdd(&s_n, mine);
+        __syncthreads();
+        if (tid == 0u) p.out_cnt[row] = s_n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// score / distance rows from physical to ORIGINAL candidate order (fz_score_all, fz_distance_all)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fz_unpermute_rows(const T *__restrict__ in, uint64_t in_stride, T *__restrict__ out,
+                                                         uint64_t out_stride, const uint32_t *__restrict__ phys_of_orig, uint32_t n)
+{
+    const T *src = in + (uint64_t)blockIdx.y * in_stride;
+    T *dst = out + (uint64_t)blockIdx.y * out_stride;
+    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) dst[o] = src[phys_of_orig[o]];
+}
+
+hipError_t fz_launch_unpermute(const void *in, uint64_t in_stride, void *out, uint64_t out_stride, const uint32_t *phys_of_orig,
+                               uint32_t n, uint32_t rows, uint32_t elem_bytes, hipStream_t st)
+{
+    if (rows == 0u || n == 0u) return hipSuccess;
+    const uint32_t bx = (n + 255u) / 256u;
+    for (uint32_t r0 = 0u; r0 < rows; r0 += FZ_GRID_Y_MAX) {
+        const uint32_t cnt = rows - r0 < FZ_GRID_Y_MAX ? rows - r0 : FZ_GRID_Y_MAX;
+        const dim3 grid(bx < 4096u ? bx : 4096u, cnt);
+        if (elem_bytes == 1u)
+            hipLaunchKernelGGL(fz_unpermute_rows<uint8_t>, grid, dim3(256), 0, st, static_cast<const uint8_t *>(in) + (uint64_t)r0 * in_stride, in_stride,
+                               static_cast<uint8_t *>(out) + (uint64_t)r0 * out_stride, out_stride, phys_of_orig, n);
+        else
+            hipLaunchKernelGGL(fz_unpermute_rows<uint16_t>, grid, dim3(256), 0, st, static_cast<const uint16_t *>(in) + (uint64_t)r0 * in_stride, in_stride,
+                               static_cast<uint16_t *>(out) + (uint64_t)r0 * out_stride, out_stride, phys_of_orig, n);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t fz_launch_merge(const FzMergeParams &p, uint32_t rows, hipStream_t st)
+{
+    if (rows == 0u || p.k == 0u) return hipSuccess;
+    uint32_t P = 2u;
+    while (P < p.k + p.cap) P <<= 1;
+    const size_t lds = (size_t)P * 8u;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_merge_lists), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fz_merge_lists, dim3(rows), dim3(256), lds, st, p);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1731,7 +1903,8 @@ hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq,
 hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st)
 {
     if (rows == 0u || p.k == 0u) return hipSuccess;
-    hipLaunchKernelGGL(fz_select_topk, dim3(rows), dim3(SEL_THREADS), 0, st, p);
+    if (p.n <= 262144u) hipLaunchKernelGGL(fz_select_topk<256u>, dim3(rows), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(fz_select_topk<1024u>, dim3(rows), dim3(1024), 0, st, p);
     return hipGetLastError();
 }
 
