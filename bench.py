@@ -170,6 +170,10 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.35)
     ap.add_argument("--latency-reps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["auto", "rccl", "torch"], default="auto",
+                    help="N > 1: who carries the all-gather + merge.  rccl: inside the library (ncclAllGather on the corpus' "
+                         "stream + device merge, fz_query_topk_sharded); torch: torch.distributed all-gather + host merge; "
+                         "auto: rccl, torch if the communicator cannot be made.  At --gpus 1, rccl runs a communicator of size 1")
     args = ap.parse_args()
 
     import torch
@@ -245,8 +249,22 @@ def main():
         gathered = torch.zeros(world * nq * k, dtype=torch.int64, device="cpu" if rehearsal else "cuda")
 
     exch = {"gather_ms": 0.0, "merge_ms": 0.0}
+    comm, comm_note = None, None
+    if (world > 1 and not rehearsal and args.exchange in ("auto", "rccl")) or (world == 1 and args.exchange == "rccl"):
+        from tts_amd._lib import FuzzyHipError
+        from tts_amd.sharded import LibraryExchange, comm_id_via_torch
+        try:
+            comm = LibraryExchange(rank, world, local_rank, comm_id_via_torch() if world > 1 else (lambda my_id: my_id))
+        except FuzzyHipError as e:
+            if args.exchange == "rccl":
+                raise
+            comm_note = f"library communicator not made ({e}); torch.distributed carries the exchange"
 
     def step():
+        if comm is not None:
+            out = corpus.topk_sharded(comm.handle, q_packed, min_score, k)
+            exch["gather_ms"] += corpus.timing()["exchange_ms"]
+            return out
         if world == 1:
             return corpus.topk(q_packed, min_score, k)
         corpus.topk_keys_device(q_packed, min_score, k, keys_dev.data_ptr(), 0, sync=True)
@@ -268,7 +286,7 @@ def main():
     for _ in range(args.warmup):
         step()
     score_ms = select_ms = prep_ms = 0.0
-    launches = 0
+    launches = fused_steps = fallback_chunks = 0
     exch["gather_ms"] = exch["merge_ms"] = 0.0
     fence()
     t0 = time.perf_counter()
@@ -277,6 +295,7 @@ def main():
         t = corpus.timing()
         score_ms += t["score_ms"]; select_ms += t["select_ms"]; prep_ms += t["host_prep_ms"]
         launches += t["score_launches"]
+        fused_steps += t["fused"]; fallback_chunks += t["fused_fallback_chunks"]
     fence()
     elapsed = time.perf_counter() - t0
     alg_local = float(synth.algorithmic_bytes_per_query(info))
@@ -303,7 +322,7 @@ def main():
         peak = valu_peak()
         roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave64 VALU instructions/s",
                 "frac": None, "traffic": None,
-                "kernel": "fz_score_stream_pk + fz_score_stream<1> + fz_score_stream<2> (one score phase, side by side)",
+                "kernel": "fz_score_stream_pk + fz_score_stream<1> + fz_score_stream<2> (the score launches of a step: sample tiles, then the rest)",
                 "kernel_ms_per_step": score_ms / steps, "launches_per_step": launches / steps,
                 "how": "achieved = VALU instructions of the score kernels per step (rocprofv3 --pmc SQ_INSTS_VALU, "
                        "profiles/pmc_current.json, quoted only when its source hash and workload match this run) / the score "
@@ -361,12 +380,23 @@ def main():
             "roofline_hbm": hbm,
             "kernel_ms_per_step": {"score": score_ms / steps, "select": select_ms / steps, "host_query_prep": prep_ms / steps},
             "kernel_pairs_per_s": float(nq) * n_local / score_s if score_s > 0 else None,
+            # fused: sample tiles -> per-row limit -> appended lists -> merge (no score matrix); matrix: u8 score matrix + select
+            "topk_path": "fused" if fused_steps == args.steps else ("matrix" if fused_steps == 0 else "mixed"),
+            "fused_chunks_redone_through_matrix": fallback_chunks,
             "setup_seconds": setup_s,
             "source_hash": source_hash(),
         }
-        if world > 1:
-            out["exchange"] = {"bytes_per_rank_per_step": nq * k * 8, "all_gather_ms_per_step": exch["gather_ms"] / steps,
-                               "host_merge_ms_per_step": exch["merge_ms"] / steps}
+        if world > 1 or comm is not None:
+            if comm is not None:
+                out["exchange"] = {"carrier": "libfuzzyhip: ncclAllGather (RCCL) on the corpus' stream + fz_merge_gathered on the device",
+                                   "bytes_per_rank_per_step": nq * k * 8,
+                                   "all_gather_plus_device_merge_ms_per_step": exch["gather_ms"] / steps}
+            else:
+                out["exchange"] = {"carrier": "torch.distributed all_gather_into_tensor + fz_merge_topk on the host",
+                                   "bytes_per_rank_per_step": nq * k * 8, "all_gather_ms_per_step": exch["gather_ms"] / steps,
+                                   "host_merge_ms_per_step": exch["merge_ms"] / steps}
+                if comm_note:
+                    out["exchange"]["note"] = comm_note
         if world == 1 and args.latency_reps > 0:
             lat = []
             for i in range(args.latency_reps):
@@ -376,6 +406,8 @@ def main():
                 lat.append((time.perf_counter() - t1) * 1e3)
             out["p50_latency_ms"] = float(np.median(lat))
             out["p50_latency_config"] = f"1 query, k={k}, {n_local} resident candidates, {args.latency_reps} calls"
+    if comm is not None:
+        comm.close()
     corpus.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cps, offs, queries, min_score, k)

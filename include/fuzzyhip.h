@@ -35,7 +35,8 @@ enum {
     FZ_ERR_ALPHABET = -3,  /* corpus has more distinct code points than the symbol table holds */
     FZ_ERR_TOO_LONG = -4,  /* query pattern / candidate longer than the kernels support */
     FZ_ERR_LIMIT = -5,     /* k or another size beyond a documented limit */
-    FZ_ERR_NO_DEVICE = -6  /* no usable GPU */
+    FZ_ERR_NO_DEVICE = -6, /* no usable GPU */
+    FZ_ERR_COMM = -7       /* librccl could not be opened, or an RCCL call failed (message has its error string) */
 };
 
 /* scorers; names follow thefuzz.fuzz (the library the reference calls) */
@@ -90,6 +91,8 @@ typedef struct {
     double host_prep_ms;/* wall time spent building query tables on the host */
     uint32_t fused;     /* 1: the last top-k call ran fused (sample + append lists, no score matrix over the shard) */
     uint32_t fused_fallback_chunks; /* chunks of that call redone through the score matrix (list overflow) */
+    float exchange_ms;  /* fz_query_topk_sharded: hipEvent time of the all-gather + device merge (0 otherwise) */
+    uint32_t reserved;
 } fz_timing;
 
 /* library version (FZ_VERSION of the build) */
@@ -209,6 +212,31 @@ int fz_query_topk_pair(fz_corpus *ca, int scorer_a, const uint32_t *qa_cps, cons
  */
 int fz_merge_topk(const uint64_t *keys, uint32_t n_lists, uint32_t nq, uint32_t k,
                   uint64_t *out_idx, int32_t *out_score, uint32_t *out_cnt);
+
+/*
+ * The exchange inside the library ("one ncclAllGather per query batch"): one process per
+ * GPU, each with its shard in an fz_corpus (contiguous index ranges, `base_index`), and ONE collective per
+ * batch: the all-gather of every rank's nq*k packed keys over RCCL (xGMI), issued on the corpus' stream
+ * right behind the top-k kernels, followed by a device merge of the n_ranks lists of every query
+ * (descending key = score desc, global index asc: identical on every rank and for every n_ranks).  No
+ * counterpart in the reference (single process).  librccl is opened with dlopen at the first fz_comm_*
+ * call (FUZZYHIP_RCCL_LIB names another file), so single-GPU users never load it.
+ *
+ *   fz_comm_unique_id  rank 0 only: FZ_COMM_ID_BYTES bytes to hand to every rank by whatever launched the
+ *                      processes (torch.distributed broadcast, a file, MPI, ...)
+ *   fz_comm_create     every rank, collectively: joins the communicator on `device`
+ *   fz_query_topk_sharded  every rank, collectively, with the SAME queries: fz_query_topk over the whole
+ *                      sharded list; every rank receives the global result.  n_ranks * k <= FZ_COMM_MAX_MERGE
+ */
+typedef struct fz_comm fz_comm;
+#define FZ_COMM_ID_BYTES 128
+#define FZ_COMM_MAX_MERGE 8192u
+int fz_comm_unique_id(void *id_out);
+int fz_comm_create(const void *id, int n_ranks, int rank, int device, fz_comm **out);
+int fz_comm_destroy(fz_comm *comm);
+int fz_query_topk_sharded(fz_corpus *c, fz_comm *comm, const uint32_t *q_cps, const uint64_t *q_offs,
+                          uint32_t nq, int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx,
+                          int32_t *out_score, uint32_t *out_cnt);
 
 /*
  * fz_score_all -- every integer score of nq queries against every candidate, in ORIGINAL

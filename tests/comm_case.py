@@ -1,0 +1,95 @@
+"""Helper of tests/test_gpu_comm.py (run as a script in its own process, because the library opens ONE
+librccl per process): the sharded entry point fz_query_topk_sharded against the single-corpus top-k.
+
+    python tests/comm_case.py threads   ranks = threads of this process sharing GPU 0, FUZZYHIP_RCCL_LIB must
+                                        name tests/fake_rccl/libfake_rccl.so (2 and 3 ranks)
+    python tests/comm_case.py real      one rank, the real librccl (communicator of size 1)"""
+import os
+import sys
+import threading
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from tts_amd import Corpus, _lib, synth  # noqa: E402
+from tts_amd.sharded import LibraryExchange, shard_bounds  # noqa: E402
+
+
+def corpus_and_queries():
+    cps, offs = synth.make_corpus(6000, max_chars=64, seed=91, vocab_size=300)
+    names = synth.to_strings(cps, offs)
+    queries = synth.make_queries(cps, offs, 12, seed=92) + [names[5].split()[0], names[77], "zz qq", ""]
+    return names, queries
+
+
+def expected(names, queries, cases):
+    out = {}
+    with Corpus.from_prepared(names) as c:
+        for sc, ms, k in cases:
+            out[(sc, ms, k)] = c.topk(queries, ms, k, sc)
+    return out
+
+
+def same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def run_threads(n_ranks, names, queries, cases, exp):
+    box, ready = {}, threading.Event()
+
+    def share(my_id):
+        if my_id is not None:
+            box["id"] = my_id
+            ready.set()
+            return my_id
+        assert ready.wait(60)
+        return box["id"]
+
+    errors, results = [], {}
+
+    def rank_main(rank):
+        try:
+            lo, hi = shard_bounds(len(names), n_ranks, rank)
+            with Corpus.from_prepared(names[lo:hi], device=0, base_index=lo) as shard:
+                comm = LibraryExchange(rank, n_ranks, 0, share)
+                for case in cases:
+                    sc, ms, k = case
+                    results[(rank, case)] = shard.topk_sharded(comm.handle, queries, ms, k, sc)
+                comm.close()
+        except Exception as e:          # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(n_ranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in ts), "a rank did not finish"
+    for r in range(n_ranks):
+        for case in cases:
+            assert same(results[(r, case)], exp[case]), (n_ranks, r, case)
+
+
+def main():
+    mode = sys.argv[1]
+    names, queries = corpus_and_queries()
+    cases = [(_lib.TOKEN_SET, 35, 10), (_lib.TOKEN_SET, 0, 64), (_lib.RATIO, 50, 7), (_lib.TOKEN_SET, 100, 5)]
+    exp = expected(names, queries, cases)
+    if mode == "threads":
+        assert "fake_rccl" in os.environ.get("FUZZYHIP_RCCL_LIB", "")
+        for n_ranks in (2, 3):
+            run_threads(n_ranks, names, queries, cases, exp)
+    else:
+        with Corpus.from_prepared(names) as c:
+            comm = LibraryExchange(0, 1, 0, lambda my_id: my_id)
+            for case in cases:
+                sc, ms, k = case
+                assert same(c.topk_sharded(comm.handle, queries, ms, k, sc), exp[case]), case
+            comm.close()
+    print("comm case ok:", mode)
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,7 @@ ORDER_BY_INDEX = 0x100
 MAX_K = 1024
 IDX_BITS = 40
 IDX_MASK = (1 << IDX_BITS) - 1
+COMM_ID_BYTES = 128
 
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
 c_u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -37,7 +38,8 @@ class FzTiming(ctypes.Structure):
     _fields_ = [("score_ms", ctypes.c_float), ("select_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("score_launches", ctypes.c_uint32), ("select_launches", ctypes.c_uint32),
                 ("pairs", ctypes.c_uint64), ("host_prep_ms", ctypes.c_double),
-                ("fused", ctypes.c_uint32), ("fused_fallback_chunks", ctypes.c_uint32)]
+                ("fused", ctypes.c_uint32), ("fused_fallback_chunks", ctypes.c_uint32),
+                ("exchange_ms", ctypes.c_float), ("reserved", ctypes.c_uint32)]
 
 
 # every symbol include/fuzzyhip.h declares: name -> (restype, argtypes)
@@ -72,6 +74,12 @@ _SIGNATURES = {
     "fz_distance_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_u32p, c_u64p, c_u32p, c_u64p,
                                          ctypes.c_uint64, c_u32p]),
     "fz_last_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(FzTiming)]),
+    "fz_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "fz_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.POINTER(ctypes.c_void_p)]),
+    "fz_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "fz_query_topk_sharded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32,
+                                             ctypes.c_int, ctypes.c_int32, ctypes.c_uint32, c_u64p, c_i32p, c_u32p]),
 }
 
 _lib = None

@@ -120,6 +120,19 @@ class Corpus:
                       _u64(idx), score.ctypes.data_as(_lib.c_i32p), _u32(cnt)))
         return idx[:, :k], score[:, :k], cnt[:nq]
 
+    def topk_sharded(self, comm_handle: int, queries, min_score: int, k: int, scorer: int = _lib.TOKEN_SET):
+        """Collective: top-k over the WHOLE sharded list (this corpus is one shard).  The exchange -- RCCL
+        all-gather of the packed keys and the device merge -- runs inside the library
+        (``fz_query_topk_sharded``); every rank passes the same queries and gets the same global result."""
+        q_cps, q_offs, nq = self._pack_queries(queries)
+        idx = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        score = np.zeros((nq, max(k, 1)), dtype=np.int32)
+        cnt = np.zeros(max(nq, 1), dtype=np.uint32)
+        _lib.check(self._lib.fz_query_topk_sharded(self._handle(), ctypes.c_void_p(comm_handle), _u32(q_cps), _u64(q_offs),
+                                                   nq, int(scorer), int(min_score), int(k), _u64(idx),
+                                                   score.ctypes.data_as(_lib.c_i32p), _u32(cnt)))
+        return idx[:, :k], score[:, :k], cnt[:nq]
+
     def topk_keys_device(self, queries, min_score: int, k: int, keys_ptr: int, cnt_ptr: int = 0,
                          scorer: int = _lib.TOKEN_SET, sync: bool = True) -> int:
         """Per-shard top-k as packed keys written to DEVICE memory (for the RCCL all-gather)."""

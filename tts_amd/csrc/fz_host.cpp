@@ -3,6 +3,7 @@
 // Reference path: FuzzySearch.__init__ / find_best_matches (reference src/fuzzy_search.py:10-38).
 // Nothing here scores on the CPU: without a gfx950 device every scoring entry point fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -37,6 +38,7 @@ hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st
 hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_t st);
 hipError_t fz_launch_select16(const FzSelect16Params &p, uint32_t rows, hipStream_t st);
 hipError_t fz_launch_merge(const FzMergeParams &p, uint32_t rows, hipStream_t st);
+hipError_t fz_launch_merge_gathered(const uint64_t *all, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t *out, hipStream_t st);
 hipError_t fz_launch_unpermute(const void *in, uint64_t in_stride, void *out, uint64_t out_stride, const uint32_t *phys_of_orig,
                                uint32_t n, uint32_t rows, uint32_t elem_bytes, hipStream_t st);
 hipError_t fz_scratch_acquire(int device, void **ptr, size_t *bytes);
@@ -1898,6 +1900,165 @@ static int fz_distance_batch_impl(int device, int kind, const uint32_t *a_cps, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// the exchange of the sharded path inside the library: RCCL all-gather + device merge (fuzzyhip.h)
+// ---------------------------------------------------------------------------------------------
+// librccl is opened at run time; the few declarations used are restated here (rccl.h: NCCL_UNIQUE_ID_BYTES
+// 128, ncclSuccess 0, ncclUint64 5) so that neither the library nor its CPU sanitizer build needs the header.
+namespace rccl {
+struct UniqueId { char internal[FZ_COMM_ID_BYTES]; };
+typedef struct ncclComm *Comm;
+typedef int (*GetUniqueId)(UniqueId *);
+typedef int (*CommInitRank)(Comm *, int, UniqueId, int);
+typedef int (*CommDestroy)(Comm);
+typedef int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t);
+typedef const char *(*GetErrorString)(int);
+constexpr int kUint64 = 5;
+struct Api {
+    void *handle = nullptr;
+    GetUniqueId get_unique_id = nullptr; CommInitRank comm_init_rank = nullptr; CommDestroy comm_destroy = nullptr;
+    AllGather all_gather = nullptr; GetErrorString get_error_string = nullptr;
+};
+static Api g_api;
+static std::mutex g_api_mu;
+
+static int load()
+{
+    std::lock_guard<std::mutex> lk(g_api_mu);
+    if (g_api.handle) return FZ_OK;
+    const char *names[3] = {getenv("FUZZYHIP_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    std::string tried;
+    for (const char *nm : names) {
+        if (!nm || !*nm) continue;
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+        const char *e = dlerror();
+        tried += std::string(tried.empty() ? "" : "; ") + nm + ": " + (e ? e : "?");
+    }
+    if (!h) return fail(FZ_ERR_COMM, "librccl could not be opened (%s)", tried.c_str());
+    Api a; a.handle = h;
+    a.get_unique_id = (GetUniqueId)dlsym(h, "ncclGetUniqueId");
+    a.comm_init_rank = (CommInitRank)dlsym(h, "ncclCommInitRank");
+    a.comm_destroy = (CommDestroy)dlsym(h, "ncclCommDestroy");
+    a.all_gather = (AllGather)dlsym(h, "ncclAllGather");
+    a.get_error_string = (GetErrorString)dlsym(h, "ncclGetErrorString");
+    if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather || !a.get_error_string) {
+        dlclose(h);
+        return fail(FZ_ERR_COMM, "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString");
+    }
+    g_api = a;
+    return FZ_OK;
+}
+}  // namespace rccl
+
+#define RCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        int r_ = (expr);                                                                            \
+        if (r_ != 0) return fail(FZ_ERR_COMM, "%s: %s", #expr, rccl::g_api.get_error_string(r_));   \
+    } while (0)
+
+struct fz_comm {
+    rccl::Comm comm = nullptr;
+    int n_ranks = 1, rank = 0, device = 0;
+    std::mutex mu;
+    uint64_t *d_local = nullptr, *d_all = nullptr, *d_out = nullptr, *h_out = nullptr;
+    size_t local_cap = 0, all_cap = 0, out_cap = 0, h_cap = 0;
+    ~fz_comm()
+    {
+        if (hipSetDevice(device) != hipSuccess) return;
+        if (comm) rccl::g_api.comm_destroy(comm);
+        if (d_local) (void)hipFree(d_local);
+        if (d_all) (void)hipFree(d_all);
+        if (d_out) (void)hipFree(d_out);
+        if (h_out) (void)hipHostFree(h_out);
+    }
+};
+
+static int fz_comm_unique_id_impl(void *id_out)
+{
+    if (!id_out) return fail(FZ_ERR_INVALID, "null id buffer");
+    int rc;
+    if ((rc = rccl::load()) != FZ_OK) return rc;
+    rccl::UniqueId id;
+    RCCL_TRY(rccl::g_api.get_unique_id(&id));
+    memcpy(id_out, id.internal, FZ_COMM_ID_BYTES);
+    return FZ_OK;
+}
+
+static int fz_comm_create_impl(const void *id, int n_ranks, int rank, int device, fz_comm **out)
+{
+    if (!id || !out) return fail(FZ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(FZ_ERR_INVALID, "rank %d of %d", rank, n_ranks);
+    int rc;
+    if ((rc = rccl::load()) != FZ_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FZ_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= ndev) return fail(FZ_ERR_INVALID, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<fz_comm> cm(new fz_comm());
+    cm->n_ranks = n_ranks; cm->rank = rank; cm->device = device;
+    rccl::UniqueId uid;
+    memcpy(uid.internal, id, FZ_COMM_ID_BYTES);
+    RCCL_TRY(rccl::g_api.comm_init_rank(&cm->comm, n_ranks, uid, rank));
+    *out = cm.release();
+    return FZ_OK;
+}
+
+// Local top-k keys -> all-gather on the corpus' stream -> device merge of the n_ranks lists per query ->
+// one copy of nq*k keys to the host.  Every rank ends up with the same, global, result.
+static int fz_query_topk_sharded_impl(fz_corpus *c, fz_comm *cm, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                                     int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx, int32_t *out_score,
+                                     uint32_t *out_cnt)
+{
+    if (!c || !cm) return fail(FZ_ERR_INVALID, "null corpus or communicator");
+    if (nq && k && (!out_idx || !out_score)) return fail(FZ_ERR_INVALID, "null output buffers");
+    if (c->device != cm->device) return fail(FZ_ERR_INVALID, "the corpus lives on device %d, the communicator on device %d", c->device, cm->device);
+    if (k > FZ_MAX_K) return fail(FZ_ERR_LIMIT, "k=%u exceeds FZ_MAX_K=%u", k, FZ_MAX_K);
+    if ((uint64_t)cm->n_ranks * k > FZ_COMM_MAX_MERGE)
+        return fail(FZ_ERR_LIMIT, "n_ranks * k = %llu exceeds FZ_COMM_MAX_MERGE=%u (gather with fz_query_topk_keys and merge with fz_merge_topk instead)",
+                    (unsigned long long)cm->n_ranks * k, FZ_COMM_MAX_MERGE);
+    if (nq == 0 || k == 0) {
+        if (out_cnt && nq) memset(out_cnt, 0, (size_t)nq * 4);
+        return FZ_OK;
+    }
+    std::lock_guard<std::mutex> lk(cm->mu);
+    HIP_TRY(hipSetDevice(cm->device));
+    const size_t nkeys = (size_t)nq * k;
+    auto grow = [&](uint64_t **p, size_t *cap, size_t need) -> int {
+        if (need <= *cap) return FZ_OK;
+        if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), need * 8));
+        *cap = need;
+        return FZ_OK;
+    };
+    int rc;
+    if ((rc = grow(&cm->d_local, &cm->local_cap, nkeys)) != FZ_OK) return rc;
+    if ((rc = grow(&cm->d_all, &cm->all_cap, nkeys * (size_t)cm->n_ranks)) != FZ_OK) return rc;
+    if ((rc = grow(&cm->d_out, &cm->out_cap, nkeys)) != FZ_OK) return rc;
+    if (nkeys > cm->h_cap) {
+        if (cm->h_out) { HIP_TRY(hipHostFree(cm->h_out)); cm->h_out = nullptr; cm->h_cap = 0; }
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&cm->h_out), nkeys * 8, hipHostMallocDefault));
+        cm->h_cap = nkeys;
+    }
+    // the local shard: keys on the device, rows padded with 0 (complete when the call returns)
+    if ((rc = fz_query_topk_keys_impl(c, q_cps, q_offs, nq, scorer, min_score, k, cm->d_local, nullptr, 1)) != FZ_OK) return rc;
+    std::lock_guard<std::mutex> lc(c->mu);                          // the corpus' stream and timing record
+    hipStream_t st = c->stream;
+    hipEvent_t e0 = get_event(c, 0), e1 = get_event(c, 1);
+    if (!e0 || !e1) return fail(FZ_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(e0, st));
+    RCCL_TRY(rccl::g_api.all_gather(cm->d_local, cm->d_all, nkeys, rccl::kUint64, cm->comm, st));
+    HIP_TRY(fz_launch_merge_gathered(cm->d_all, (uint32_t)cm->n_ranks, nq, k, cm->d_out, st));
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipMemcpyAsync(cm->h_out, cm->d_out, nkeys * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    { float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.exchange_ms = ms; }
+    decode_keys(cm->h_out, nq, k, out_idx, out_score, out_cnt);
+    return FZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // the C ABI: every entry point that can allocate runs inside guarded() (no exception leaves the library)
 // ---------------------------------------------------------------------------------------------
 extern "C" int fz_corpus_create(const uint32_t *cps, const uint64_t *offs, uint64_t n, int device,
@@ -1971,4 +2132,26 @@ extern "C" int fz_distance_batch(int device, int kind, const uint32_t *a_cps, co
                                  uint32_t *out_dist)
 {
     return guarded([&] { return fz_distance_batch_impl(device, kind, a_cps, a_offs, b_cps, b_offs, n_pairs, out_dist); });
+}
+
+extern "C" int fz_comm_unique_id(void *id_out)
+{
+    return guarded([&] { return fz_comm_unique_id_impl(id_out); });
+}
+
+extern "C" int fz_comm_create(const void *id, int n_ranks, int rank, int device, fz_comm **out)
+{
+    return guarded([&] { return fz_comm_create_impl(id, n_ranks, rank, device, out); });
+}
+
+extern "C" int fz_comm_destroy(fz_comm *comm)
+{
+    return guarded([&] { delete comm; return (int)FZ_OK; });
+}
+
+extern "C" int fz_query_topk_sharded(fz_corpus *c, fz_comm *comm, const uint32_t *q_cps, const uint64_t *q_offs,
+                                     uint32_t nq, int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx,
+                                     int32_t *out_score, uint32_t *out_cnt)
+{
+    return guarded([&] { return fz_query_topk_sharded_impl(c, comm, q_cps, q_offs, nq, scorer, min_score, k, out_idx, out_score, out_cnt); });
 }

@@ -1567,6 +1567,42 @@ __global__ __launch_bounds__(256) void fz_merge_lists(FzMergeParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// sharded path: the gathered key lists [n_lists][nq][k] of a query -> its global top-k (descending key)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fz_merge_gathered(const uint64_t *__restrict__ all, uint32_t n_lists, uint32_t nq,
+                                                         uint32_t k, uint64_t *__restrict__ out)
+{
+    extern __shared__ __align__(16) uint64_t s_mg[];
+    const uint32_t tid = threadIdx.x, row = blockIdx.x;
+    const uint32_t total = n_lists * k;
+    uint32_t P = 2u;
+    while (P < total) P <<= 1;
+    for (uint32_t i = tid; i < P; i += blockDim.x) {
+        uint64_t v = 0ull;                                  // padding sorts last: a real key is never 0
+        if (i < total) v = all[((uint64_t)(i / k) * nq + row) * k + (i % k)];
+        s_mg[i] = v;
+    }
+    __syncthreads();
+    fz_bitonic<uint64_t, true>(s_mg, P);
+    for (uint32_t i = tid; i < k; i += blockDim.x) out[(uint64_t)row * k + i] = s_mg[i];
+}
+
+hipError_t fz_launch_merge_gathered(const uint64_t *all, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t *out, hipStream_t st)
+{
+    if (nq == 0u || k == 0u || n_lists == 0u) return hipSuccess;
+    if ((uint64_t)n_lists * k > FZ_COMM_MAX_MERGE) return hipErrorInvalidValue;
+    uint32_t P = 2u;
+    while (P < n_lists * k) P <<= 1;
+    const size_t lds = (size_t)P * 8u;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_merge_gathered), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fz_merge_gathered, dim3(nq), dim3(256), lds, st, all, n_lists, nq, k, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // score / distance rows from physical to ORIGINAL candidate order (fz_score_all, fz_distance_all)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
