@@ -1222,6 +1222,8 @@ static int prepare_rows(fz_corpus *c, int view_kind, int kmode, const uint32_t *
     }
     const auto t_prep = std::chrono::steady_clock::now();
     for (int i = 0; i < 8; ++i) b.recs.push_back(FzRec{0, 0, 0, 0});      // the kernel prefetches records ahead
+    if (b.recs.size() >= (1ull << 28))                                    // the kernels address records by 32-bit byte offsets
+        return fail(FZ_ERR_LIMIT, "%zu stream records in one chunk of queries (limit 2^28)", b.recs.size());
     // one device blob: [FzQuery list][peq][tok_id][tok_pos][tok_len1][stream records][qrec][rows]
     for (int pass = 0; pass < 2; ++pass)
         for (auto &kv : (pass == 0 ? b.classes : b.slow_classes)) {

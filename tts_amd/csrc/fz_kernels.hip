@@ -536,6 +536,24 @@ __device__ __forceinline__ uint32_t fz_tab_load(uint32_t tab_off, uint32_t idx)
     return *(__attribute__((address_space(3))) const uint8_t *)(uintptr_t)a;   // EMUL: return *(const uint8_t *)(emul::g_lds + a);
 }
 
+// ---- loads the compiler must keep scalar --------------------------------------------------------------
+// The record stream and the row limits are written before the launch and only read by it.  A load through
+// the CONSTANT address space is invariant to the compiler, so a wave-uniform one stays a scalar load
+// (s_load_dwordx4) wherever it stands.  Through a plain pointer the EMIT kernels, whose list appends are
+// atomics, turned every record load after the first query's epilogue into global_load_dwordx4 +
+// s_waitcnt vmcnt(0) + 4 v_readfirstlane: a vector load the wave waits for on the spot, per record.
+// The byte offset stays 32-bit so that the address is base + offset in the load itself.
+__device__ __forceinline__ FzRec fz_rec_load(const FzRec *recs, uint32_t byte_off)
+{
+    typedef uint32_t fz_u32x4 __attribute__((ext_vector_type(4)));   // EMUL: ;
+    const fz_u32x4 v = *(const __attribute__((address_space(4))) fz_u32x4 *)((uintptr_t)recs + byte_off);   // EMUL: const FzRec v = *(const FzRec *)((const char *)recs + byte_off);
+    return FzRec{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ uint64_t fz_lim_load(const uint64_t *lim, uint32_t row)
+{
+    return *(const __attribute__((address_space(4))) uint64_t *)((uintptr_t)lim + 8ull * row);   // EMUL: return lim[row];
+}
+
 // ---- lane masks: a vector compare leaves one bit per lane in a scalar register pair -------------------
 // Scalar ORs combine them (no lane operation per compare), and two single instructions bring a mask back
 // into the lanes: a select, and "shift the lane's bit into a per-lane bit string" (v_addc: x + x + carry-in).
@@ -595,16 +613,16 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
     constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
-    uint32_t ri = p.qrec[q0];
-    FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with padding records
-#define FZ_ADVANCE() do { cur = nxt; nxt = recs[ri + 2u]; ++ri; } while (0)
+    uint32_t ro = p.qrec[q0] * (uint32_t)sizeof(FzRec);               // byte offset of the current record
+    FzRec cur = fz_rec_load(recs, ro), nxt = fz_rec_load(recs, ro + 16u);   // the stream ends with padding records
+#define FZ_ADVANCE() do { cur = nxt; nxt = fz_rec_load(recs, ro + 32u); ro += 16u; } while (0)
 
     for (uint32_t q = q0; q < q1; ++q) {
         const uint32_t out_row = cur.x, m = cur.y & 0xFFu;
         const uint32_t n_ids = (cur.y >> 8) & 0xFFu, nrec = cur.y >> 16;
         const uint32_t id0 = cur.z, id1 = cur.w;
         FZ_ADVANCE();
-        const uint64_t lim = EMIT ? p.emit.lim[out_row] : 0ull;         // scalar load, used at the end of the query
+        const uint64_t lim = EMIT ? fz_lim_load(p.emit.lim, out_row) : 0ull;   // scalar load, used at the end of the query
 
         uint32_t M[W], has = 0u;                         // has: bit string "the candidate has query token j"
 #pragma unroll
@@ -895,9 +913,9 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
     }
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
-    uint32_t ri = p.qrec[q0];
-    FzRec cur = recs[ri], nxt = recs[ri + 1u];          // the stream ends with padding records
-#define FZ_ADVANCE() do { cur = nxt; nxt = recs[ri + 2u]; ++ri; } while (0)
+    uint32_t ro = p.qrec[q0] * (uint32_t)sizeof(FzRec);               // byte offset of the current record
+    FzRec cur = fz_rec_load(recs, ro), nxt = fz_rec_load(recs, ro + 16u);   // the stream ends with padding records
+#define FZ_ADVANCE() do { cur = nxt; nxt = fz_rec_load(recs, ro + 32u); ro += 16u; } while (0)
 
     for (uint32_t q = q0; q < q1; ++q) {
         // record formats and the two phases: fz_stream_queries above; here every query token leaves TWO
@@ -906,7 +924,7 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
         const uint32_t n_ids = (cur.y >> 8) & 0xFFu, nrec = cur.y >> 16;
         const uint32_t id0 = cur.z, id1 = cur.w;
         FZ_ADVANCE();
-        const uint64_t lim = EMIT ? p.emit.lim[out_row] : 0ull;         // scalar load, used at the end of the query
+        const uint64_t lim = EMIT ? fz_lim_load(p.emit.lim, out_row) : 0ull;   // scalar load, used at the end of the query
 
         uint32_t M = 0xFFFFFFFFu, has = 0u;
         if (MODE == FZ_MODE_TOKEN_SET && n_ids != 0u) {
