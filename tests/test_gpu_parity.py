@@ -226,8 +226,20 @@ def test_packed_corpus_file_roundtrip(oracle, tmp_path):
 def test_workspace_chunking_and_caller_stream(oracle):
     """A tiny workspace limit forces many query chunks; a caller-provided stream carries the work:
     results must not change."""
-    import torch
-    st = torch.cuda.Stream()                     # torch's own HIP initialisation, before the library's work
+    # a stream of the caller's own, made with the HIP runtime the library itself is linked to (torch ships a
+    # second copy of the runtime; initialising that one late in a process that already works on the GPU
+    # failed now and then on the test box with hipErrorNoDevice, which says nothing about the library)
+    import ctypes
+    hip = None
+    for name in ("libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"):
+        try:
+            hip = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    assert hip is not None, "no HIP runtime to make a stream with"
+    st = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(st)) == 0
     cps, offs = synth.make_corpus(20_000, max_chars=64, seed=101)
     queries = synth.make_queries(cps, offs, 37, seed=102)
     with Corpus(cps, offs) as c:
@@ -238,11 +250,12 @@ def test_workspace_chunking_and_caller_stream(oracle):
         for a, b in zip(got, ref):
             assert (a == b).all()
         assert (c.score_all(queries[:5]) == ref_all).all()
-        c.set_stream(st.cuda_stream)
+        c.set_stream(st.value)
         got = c.topk(queries, 35, 10)
         for a, b in zip(got, ref):
             assert (a == b).all()
         c.set_stream(None)
+        assert hip.hipStreamDestroy(st) == 0
         c.set_workspace_limit(4 << 30)
         got = c.topk(queries, 35, 10, _lib.PARTIAL)
         cand = synth.to_strings(cps, offs)

@@ -613,9 +613,12 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
     constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
+    // ONE record is in flight: a consumer copies what it needs of `cur` and then asks for the next record
+    // (no cur = nxt rotation of two records: fewer scalar moves, and measured 1.5 % faster; the scalar
+    // cache answers quickly enough that a deeper prefetch buys nothing).  The stream ends with padding records.
     uint32_t ro = p.qrec[q0] * (uint32_t)sizeof(FzRec);               // byte offset of the current record
-    FzRec cur = fz_rec_load(recs, ro), nxt = fz_rec_load(recs, ro + 16u);   // the stream ends with padding records
-#define FZ_ADVANCE() do { cur = nxt; nxt = fz_rec_load(recs, ro + 32u); ro += 16u; } while (0)
+    FzRec cur = fz_rec_load(recs, ro);
+#define FZ_ADVANCE() do { ro += 16u; cur = fz_rec_load(recs, ro); } while (0)
 
     for (uint32_t q = q0; q < q1; ++q) {
         const uint32_t out_row = cur.x, m = cur.y & 0xFFu;
@@ -913,9 +916,12 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
     }
     uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
     if (q1 > p.nq) q1 = p.nq;
+    // ONE record is in flight: a consumer copies what it needs of `cur` and then asks for the next record
+    // (no cur = nxt rotation of two records: fewer scalar moves, and measured 1.5 % faster; the scalar
+    // cache answers quickly enough that a deeper prefetch buys nothing).  The stream ends with padding records.
     uint32_t ro = p.qrec[q0] * (uint32_t)sizeof(FzRec);               // byte offset of the current record
-    FzRec cur = fz_rec_load(recs, ro), nxt = fz_rec_load(recs, ro + 16u);   // the stream ends with padding records
-#define FZ_ADVANCE() do { cur = nxt; nxt = fz_rec_load(recs, ro + 32u); ro += 16u; } while (0)
+    FzRec cur = fz_rec_load(recs, ro);
+#define FZ_ADVANCE() do { ro += 16u; cur = fz_rec_load(recs, ro); } while (0)
 
     for (uint32_t q = q0; q < q1; ++q) {
         // record formats and the two phases: fz_stream_queries above; here every query token leaves TWO
