@@ -99,11 +99,13 @@ struct FzScoreParams {
 //           vocabulary, the only ones that can intersect, in token order
 //   tokens  {4 row bytes, 4 row bytes, 4 row bytes, meta}: up to 12 text symbols of one token, each byte =
 //           4 * (Peq row of the symbol), padded with 0 (row 0 is all zero in every column, so a step on it
-//           changes nothing) up to the 4, 8 or 12 steps of the record's class; meta = class | known << 2 |
-//           last << 3 | first << 4; a longer token continues in the next record.  `known` says the token has
-//           a vocabulary id (it takes one bit, two in the packed kernel, off the lane's "candidate has
-//           this token" string), `last` that the separator step follows (token_set only).  Symbols no
-//           candidate uses are dropped on the host: they cannot change the LCS state.
+//           changes nothing) up to the 4, 8 or 12 steps of the record's class; meta = class | last << 3 |
+//           first << 4 | (2 * tpos) << 8; a longer token continues in the next record.  tpos is the bit of the
+//           lane's "candidate has this token" string that belongs to the token (the kernels shift one bit per
+//           id into the string, two in the packed kernel: bits 2*tpos + 1 and 2*tpos); a token without a
+//           vocabulary id points at bit 15, beyond any string.  `last` says the separator step follows
+//           (token_set only).  Symbols no candidate uses are dropped on the host: they cannot change the LCS
+//           state.
 #define FZ_STREAM_MAX_TOK 8u      // token slots of an eligible tile
 #define FZ_PK_MAX_TOK 4u          // ... of a tile the packed kernel takes (two tiles per wave, <= 31 symbols together)
 #define FZ_PK_SPLIT_SHIFT 27u     // packed tile list: entry 2i = tile A | split << 27, entry 2i + 1 = tile B

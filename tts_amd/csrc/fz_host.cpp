@@ -966,14 +966,19 @@ static bool stream_append(QueryBatch &b, bool token_set, uint32_t out_row, uint3
         for (uint32_t k = 0; k < 4 && j + k < n_ids; ++k) (&r.x)[k] = known[j + k];
         b.recs.push_back(r);
     }
-    // token records {symbols 0-3, 4-7, 8-11 as row bytes (0 = the all-zero row: padding), class | known << 2 |
-    // last << 3 | first << 4}: the kernel runs 4, 8 or 12 steps by class, so that no branch depends on the length
-    uint32_t nrec = 0;
+    // token records {symbols 0-3, 4-7, 8-11 as row bytes (0 = the all-zero row: padding), class | last << 3 |
+    // first << 4 | 2 * tpos << 8}: the kernel runs 4, 8 or 12 steps by class, so that no branch depends on the
+    // length.  tpos is where the lanes keep "the candidate has this token": the kernels shift one bit per known
+    // id into a per-lane string (two in the packed kernel), so the k-th known token of n sits at bit n - 1 - k;
+    // a token without a vocabulary id points at bit 15, which no string of <= 15 ids reaches (always zero).
+    uint32_t nrec = 0, k_known = 0;
     const size_t ntok = tok_first.size() - 1;
     for (size_t t = 0; t < ntok; ++t) {
         const uint32_t a = tok_first[t], e = tok_first[t + 1];
         uint32_t pos = a;
         bool first = true;
+        uint32_t tpos = 15u;
+        if (token_set && ids[t] != FZ_QTOK_UNKNOWN) tpos = n_ids - 1u - k_known++;
         do {                                             // an empty token still owns its separator step
             const uint32_t n = std::min<uint32_t>(12u, e - pos);
             FzRec r{0u, 0u, 0u, n <= 4u ? 0u : (n <= 8u ? 1u : 2u)};
@@ -981,7 +986,7 @@ static bool stream_append(QueryBatch &b, bool token_set, uint32_t out_row, uint3
                 (&r.x)[k >> 2] |= (uint32_t)b.row_of_sym[text[pos + k]] << (8u * (k & 3u));
             pos += n;
             if (first) r.w |= 16u;
-            if (first && token_set && ids[t] != FZ_QTOK_UNKNOWN) r.w |= 4u;
+            r.w |= (2u * tpos) << 8;                     // a continuation record repeats its token's position
             if (pos >= e) r.w |= 8u;                     // last record of the token
             b.recs.push_back(r);
             ++nrec;

@@ -565,6 +565,12 @@ __device__ __forceinline__ uint32_t fz_shift_in(uint32_t bits, uint64_t mask)
     return bits;
 }
 
+// bit `pos` (a scalar) of x, spread over the whole word: one v_bfe_i32
+__device__ __forceinline__ uint32_t fz_bit_spread(uint32_t x, uint32_t pos)
+{
+    return (uint32_t)__builtin_amdgcn_sbfe((int)x, pos, 1u);   // EMUL: return 0u - ((x >> pos) & 1u);
+}
+
 // this lane's bit of `mask` set ? a : all ones
 __device__ __forceinline__ uint32_t fz_ones_unless(uint64_t mask, uint32_t a)
 {
@@ -599,9 +605,10 @@ __device__ __forceinline__ void fz_stream_step(uint32_t (&V)[W], const uint32_t 
 // Phase 1 compares every query id with the NT candidate ids (lane masks, fz_eq_mask): a candidate token the
 // query also has leaves the pattern (its range is cleared in M), and whether the CANDIDATE has query token j
 // is shifted into a per-lane bit string, one bit per known query token, in token order.  Phase 2 scans the
-// tokens: a known token takes its bit off the top of that string and is scanned with an all-zero mask when
-// the bit is set (a token both sides have is in neither difference).  No lane operation depends on the
-// number of symbols: the only scalar branches of a token are its step class and its flags.
+// tokens: every token record names its token's bit of that string (a token without an id names a bit that is
+// always zero) and is scanned with an all-zero mask when the bit is set (a token both sides have is in
+// neither difference) -- one v_bfe_i32 per record, no branch on "known" or "first".  No lane operation depends
+// on the number of symbols: the only scalar branches of a token are its step class and its last-record flag.
 template <int W, int MODE, int STRIDE, int NT, bool EMIT>
 __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const FzRec *__restrict__ recs,
                                                   uint8_t *__restrict__ scores, const uint8_t *s_tab,
@@ -656,25 +663,21 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int w = 0; w < W; ++w) M[w] &= fz_ones_unless(hit[i], ~Rm[i][w]);
-            has <<= 32u - n_ids;                                      // the first token's bit on top
         }
 
         uint32_t V[W], Mk[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) { V[w] = 0xFFFFFFFFu; Mk[w] = M[w]; }
         for (uint32_t r = 0; r < nrec; ++r) {
-            // token record {symbols 0-3, symbols 4-7, symbols 8-11, class | known << 2 | last << 3 | first << 4}
+            // token record {symbols 0-3, symbols 4-7, symbols 8-11, class | last << 3 | first << 4 | 2 * tpos << 8}
             const uint32_t s0 = cur.x, s1 = cur.y, s2 = cur.z, meta = cur.w;
-            if (MODE == FZ_MODE_TOKEN_SET && (meta & 16u)) {
-                if (meta & 4u) {
-                    const uint32_t t = (uint32_t)((int32_t)has >> 31);      // all ones: both sides have the token
-                    has <<= 1;
+            if (MODE == FZ_MODE_TOKEN_SET) {
+                // the token's bit of the lane string, spread over the word: all ones when both sides have the
+                // token, which is then scanned with an all-zero mask.  No branch: a token without an id reads
+                // a bit that is always zero, a continuation record repeats its token's position.
+                const uint32_t t = fz_bit_spread(has, (meta >> 9) & 15u);
 #pragma unroll
-                    for (int w = 0; w < W; ++w) Mk[w] = M[w] & ~t;
-                } else {
-#pragma unroll
-                    for (int w = 0; w < W; ++w) Mk[w] = M[w];
-                }
+                for (int w = 0; w < W; ++w) Mk[w] = M[w] & ~t;
             }
             // LDS rows of this lane's column: column address + row byte (one SDWA add each).  All rows of the
             // record are in flight before its first step: the empty asm pins them there, and its memory
@@ -962,7 +965,6 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int i = 0; i < NT; ++i) M &= fz_ones_unless(hit[h][i], nRm[h][i]);
-            has <<= 32u - 2u * n_ids;                                 // the first token's two bits on top
         }
 
         uint32_t V = 0xFFFFFFFFu, Mk = M;
@@ -970,10 +972,9 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
             const uint32_t s0 = cur.x, s1 = cur.y, s2 = cur.z, meta = cur.w;
             // the mask of the token (issued between the row reads and the wait for them): a token both sides
             // have is scanned with a zero mask, per half: Mk = M & ~(tA & fieldA) & ~(tB & fieldB)
-#define FZ_MK() do { if (MODE == FZ_MODE_TOKEN_SET && (meta & 16u)) { \
-                         if (meta & 4u) { const uint32_t tA = (uint32_t)((int32_t)has >> 31), tB = (uint32_t)((int32_t)(has << 1) >> 31); has <<= 2; \
-                                          Mk = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(M, tA, fm[0], 0x70), tB, fm[1], 0x70); } \
-                         else Mk = M; } } while (0)
+#define FZ_MK() do { if (MODE == FZ_MODE_TOKEN_SET) { const uint32_t pos_ = (meta >> 8) & 31u; \
+                         const uint32_t tA = fz_bit_spread(has >> 1, pos_), tB = fz_bit_spread(has, pos_); \
+                         Mk = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(M, tA, fm[0], 0x70), tB, fm[1], 0x70); } } while (0)
             uint32_t row[12];
 #define FZ_ROWS4(g, word) do { const uint32_t o_[4] = {fz_add_byte<0>((word), col_off), fz_add_byte<1>((word), col_off), fz_add_byte<2>((word), col_off), fz_add_byte<3>((word), col_off)}; \
                                _Pragma("unroll") for (int k = 0; k < 4; ++k) row[4 * (g) + k] = fz_lds_load(o_[k]); } while (0)
