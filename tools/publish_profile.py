@@ -86,7 +86,7 @@ def derive():
         "dominant_score_kernel": main_k,
         "salu_insts_per_cu_cycle_dominant": per[main_k]["salu_insts_per_cu_cycle"],
         "valu_issue_frac_2cyc_dominant": per[main_k]["valu_issue_frac_2cyc"],
-        "queries_per_tile_pass": 32,
+        "queries_per_tile_pass": ">= 32 (a work item takes one tile, or pair of tiles, through a group of 32 to 256 queries out of LDS; 200 at C2)",
         "per_kernel": per,
     }
 

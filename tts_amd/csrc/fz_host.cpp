@@ -206,7 +206,8 @@ struct fz_corpus {
     uint64_t slab_bytes = 24ull << 20;                    // FUZZYHIP_SLAB_KB: corpus bytes one stream kernel keeps cache resident
     uint32_t stream_oversub = 1;                          // FUZZYHIP_STREAM_OVERSUB: persistent blocks per slot
     uint32_t pipe_chunks = 1;                             // FUZZYHIP_CHUNKS: pieces of a large top-k batch
-    uint32_t stream_waves = 16, stream_blocks = 3072;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
+    uint32_t stream_waves = 16, stream_blocks = 1536;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
+    uint32_t stream_max_group = 256;                      // most queries one work item takes (FUZZYHIP_STREAM_MAX_GROUP)
     std::vector<hipEvent_t> events;
     fz_timing timing{};
     std::mutex mu;
@@ -615,6 +616,7 @@ static int finish_create(fz_corpus *c)
     if (const char *e = getenv("FUZZYHIP_SLAB_KB")) c->slab_bytes = (uint64_t)std::max(1, atoi(e)) << 10;
     if (const char *e = getenv("FUZZYHIP_STREAM_WAVES")) c->stream_waves = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("FUZZYHIP_STREAM_BLOCKS")) c->stream_blocks = (uint32_t)std::max(1, atoi(e));
+    if (const char *e = getenv("FUZZYHIP_STREAM_MAX_GROUP")) c->stream_max_group = (uint32_t)std::max(32, atoi(e));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = (uint32_t)prop.multiProcessorCount;
@@ -1367,6 +1369,8 @@ static int launch_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, cons
             // enough blocks to balance the chip, enough queries per block to amortise the tile set-up
             const uint64_t bx = (units + p.nwaves - 1) / p.nwaves;
             uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (c->stream_blocks + bx - 1) / bx));
+            // ... and no item so long that the launch ends in a tail of it (a large batch over a large shard)
+            by = std::max<uint64_t>(by, (p.nq + c->stream_max_group - 1) / c->stream_max_group);
             p.q_per_block = (uint32_t)((p.nq + by - 1) / by);
             const uint64_t groups = (p.nq + p.q_per_block - 1) / p.q_per_block;
             if ((uint64_t)units * groups > 0xFFFFFF00ull) return fail(FZ_ERR_LIMIT, "too many work items in one launch");
