@@ -76,6 +76,14 @@ def test_c2_full_corpus_vs_oracle(fast_oracle):
                 e = _topk_from_matrix(exp[qi], min_score, k)
                 g = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
                 assert g == e, (queries[qi], min_score, k, g[:4], e[:4])
+        # FZ_ORDER_BY_INDEX (the first passing candidates in list order, reference app.py:1009-1011) on the same
+        # rows: a small batch over a large shard also takes the sliced select, whose walk in original order
+        # must stay inside each slice
+        for min_score, k in ((35, 10), (100, 3)):
+            idx, score, cnt = c.topk(queries, min_score, k, _lib.TOKEN_SET | _lib.ORDER_BY_INDEX)
+            for qi in range(len(queries)):
+                e = [int(i) for i in np.nonzero(exp[qi] >= min_score)[0][:k]]
+                assert [int(idx[qi, j]) for j in range(int(cnt[qi]))] == e, (queries[qi], min_score, k)
 
 
 def test_c4_long_strings_vs_oracle(fast_oracle):
