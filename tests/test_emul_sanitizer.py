@@ -178,6 +178,21 @@ def test_fused_topk_sample_and_lists(oracle, runner, tmp_path):
             assert got == exp, (sk, k, ms, q, got[:5], exp[:5])
 
 
+def test_query_tables_built_by_threads(oracle, runner, tmp_path):
+    """>= 256 queries in one chunk: the host builds the query tables on several threads (stream rows handed
+    out first, per-thread batches appended with their offsets moved); token_set over the stream kernels and
+    partial_ratio over the general kernel (Peq tables and token triples of every part) against the oracle"""
+    cps, offs = synth.make_corpus(70, max_chars=40, seed=71, vocab_size=30)
+    cand = synth.to_strings(cps, offs) + ["", "x" * 70]
+    base = synth.make_queries(cps, offs, 37, seed=72, max_chars=40) + ["", "zz top", "y" * 70, cand[3]]
+    queries = [base[i % len(base)] for i in range(300)]
+    for sk, orc in ((0, oracle.TOKEN_SET), (3, oracle.PARTIAL)):
+        got = _run(runner, tmp_path, 0, sk, cand, queries, env={"FUZZYHIP_PREP_THREADS": "4"})
+        exp = _oracle_scores(oracle, orc, base, cand)[np.arange(300) % len(base)]
+        bad = np.argwhere(got != exp)
+        assert bad.size == 0, (sk, [(queries[q], cand[i], int(got[q, i]), int(exp[q, i])) for q, i in bad[:5]])
+
+
 def test_topk_many_ties_walk(oracle, runner, tmp_path):
     # > SEL_TIECAP equal scores at the cut: the original-order walk of fz_select_topk
     cand = ["aa bb"] * 2500 + ["aa"] * 3 + ["cc"] * 20
