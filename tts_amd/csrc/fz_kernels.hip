@@ -89,6 +89,26 @@ __device__ __forceinline__ void fz_emit(const FzEmit &e, uint32_t row, uint64_t 
 }
 
 // clear bits [s, e) (e > s) of a per-lane bit row stored word-major with stride 64 (row[w*64])
+// One word of the W-word Hyyro update with the carry of the big addition kept where the hardware keeps it: a
+// lane mask in a scalar register pair, produced by v_add_co / v_addc_co and consumed by the next word's
+// v_addc_co.  Written as 64-bit arithmetic the compiler materialises every carry (v_cndmask 0/1, a zero
+// high word, v_lshl_add_u64): about 14 instructions per word instead of 3.
+//   u = v & row & keep;  t = v + u + carry;  v = t | (v ^ u)
+template <bool FIRST>
+__device__ __forceinline__ uint32_t fz_lcs_word(uint32_t v, uint32_t row, uint32_t keep, uint64_t &carry)
+{
+    const uint32_t u = __builtin_amdgcn_bitop3_b32(v, row, keep, 0x80);
+    uint32_t t;
+    uint64_t co;
+    if constexpr (FIRST) {
+        asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t), "=s"(co) : "v"(v), "v"(u));   // EMUL: { const uint64_t t_ = (uint64_t)v + u; t = (uint32_t)t_; co = t_ >> 32; }
+    } else {
+        asm("v_addc_co_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(co) : "v"(v), "v"(u), "s"(carry));   // EMUL: { const uint64_t t_ = (uint64_t)v + u + (carry & 1ull); t = (uint32_t)t_; co = t_ >> 32; }
+    }
+    carry = co;
+    return __builtin_amdgcn_bitop3_b32(t, v, u, 0xF6);
+}
+
 __device__ __forceinline__ void fz_clear_bits(uint32_t *row, uint32_t s, uint32_t e)
 {
     uint32_t w0 = s >> 5, w1 = (e - 1u) >> 5;
@@ -277,14 +297,10 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
                 uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
                 if (((tkw >> k) & 1u) == 0u) s = FZ_SYM_NULL;  // removed token: no match, no change
                 const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
-                uint32_t carry = 0u;
+                uint64_t carry = 0ull;
+                V[0] = fz_lcs_word<true>(V[0], row[0], M[0], carry);
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    const uint32_t u = V[w] & row[w] & M[w];
-                    const uint64_t t = (uint64_t)V[w] + (uint64_t)u + (uint64_t)carry;
-                    carry = (uint32_t)(t >> 32);
-                    V[w] = (uint32_t)t | (V[w] ^ u);
-                }
+                for (int w = 1; w < W; ++w) V[w] = fz_lcs_word<false>(V[w], row[w], M[w], carry);
             }
             tkw >>= SY::SPD;
         }
@@ -375,14 +391,10 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
                     if (j == i || (j % (uint32_t)SY::SPD) == 0u) cw = symp[(j / (uint32_t)SY::SPD) * 64u];
                     const uint32_t s = (cw >> ((uint32_t)SY::BITS * (j % (uint32_t)SY::SPD))) & SY::MASK;
                     const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
-                    uint32_t carry = 0u;
+                    uint64_t carry = 0ull;
+                    V[0] = fz_lcs_word<true>(V[0], row[0], 0xFFFFFFFFu, carry);
 #pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        const uint32_t u = V[w] & row[w];
-                        const uint64_t t = (uint64_t)V[w] + (uint64_t)u + (uint64_t)carry;
-                        carry = (uint32_t)(t >> 32);
-                        V[w] = (uint32_t)t | (V[w] ^ u);
-                    }
+                    for (int w = 1; w < W; ++w) V[w] = fz_lcs_word<false>(V[w], row[w], 0xFFFFFFFFu, carry);
                     if (i == 0u && j + 1u < m) {               // proper prefix window l[:j+1]
                         uint32_t l = 0u;
 #pragma unroll
@@ -412,16 +424,13 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
                     for (int k = 0; k < SY::SPD; ++k) {
                         const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
                         const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
-                        uint32_t carry = 0u;
+                        uint64_t carry = 0ull;
 #pragma unroll
                         for (int w = 0; w < W; ++w) {
                             // pattern bits below i are masked off: they belong to no window of this pass
                             const uint32_t lo = (uint32_t)w * 32u;
                             const uint32_t keep = i <= lo ? 0xFFFFFFFFu : (i >= lo + 32u ? 0u : (0xFFFFFFFFu << (i - lo)));
-                            const uint32_t u = V[w] & row[w] & keep;
-                            const uint64_t t = (uint64_t)V[w] + (uint64_t)u + (uint64_t)carry;
-                            carry = (uint32_t)(t >> 32);
-                            V[w] = (uint32_t)t | (V[w] ^ u);
+                            V[w] = w == 0 ? fz_lcs_word<true>(V[w], row[w], keep, carry) : fz_lcs_word<false>(V[w], row[w], keep, carry);
                         }
                     }
                 }
