@@ -109,6 +109,21 @@ __device__ __forceinline__ uint32_t fz_lcs_word(uint32_t v, uint32_t row, uint32
     return __builtin_amdgcn_bitop3_b32(t, v, u, 0xF6);
 }
 
+// a + b + carry with the carry as a lane mask (the adder of the Myers / Hyyro Levenshtein recurrence)
+template <bool FIRST>
+__device__ __forceinline__ uint32_t fz_add_carry(uint32_t a, uint32_t b, uint64_t &carry)
+{
+    uint32_t t;
+    uint64_t co;
+    if constexpr (FIRST) {
+        asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(t), "=s"(co) : "v"(a), "v"(b));   // EMUL: { const uint64_t t_ = (uint64_t)a + b; t = (uint32_t)t_; co = t_ >> 32; }
+    } else {
+        asm("v_addc_co_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(co) : "v"(a), "v"(b), "s"(carry));   // EMUL: { const uint64_t t_ = (uint64_t)a + b + (carry & 1ull); t = (uint32_t)t_; co = t_ >> 32; }
+    }
+    carry = co;
+    return t;
+}
+
 __device__ __forceinline__ void fz_clear_bits(uint32_t *row, uint32_t s, uint32_t e)
 {
     uint32_t w0 = s >> 5, w1 = (e - 1u) >> 5;
@@ -258,14 +273,14 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
                     if (d * (uint32_t)SY::SPD + (uint32_t)k < clen && q.m != 0u) {     // padding is not text here
                         const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
                         const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
-                        uint32_t carry = 0u, phc = 1u, mhc = 0u;
+                        uint64_t carry = 0ull;
+                        uint32_t phc = 1u, mhc = 0u;
 #pragma unroll
                         for (int w = 0; w < W; ++w) {
                             const uint32_t Eq = row[w];
                             const uint32_t Xv = Eq | Mv[w];
-                            const uint64_t t = (uint64_t)(Eq & Pv[w]) + (uint64_t)Pv[w] + (uint64_t)carry;
-                            carry = (uint32_t)(t >> 32);
-                            const uint32_t Xh = ((uint32_t)t ^ Pv[w]) | Eq;
+                            const uint32_t t = w == 0 ? fz_add_carry<true>(Eq & Pv[w], Pv[w], carry) : fz_add_carry<false>(Eq & Pv[w], Pv[w], carry);
+                            const uint32_t Xh = (t ^ Pv[w]) | Eq;
                             uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
                             uint32_t Mh = Pv[w] & Xh;
                             if ((uint32_t)w == lastw) dist += ((Ph >> lastb) & 1u) - ((Mh >> lastb) & 1u);
