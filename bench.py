@@ -121,6 +121,24 @@ def cpu_baseline(cps, offs, queries, min_score, k, budget_s=10.0):
     return out
 
 
+def verify_rows(last, cps, offs, queries, min_score, k, rows=8):
+    """Checker (not measured): `rows` rows of the LAST timed step's output against the oracle's loop over the whole
+    corpus (reference src/fuzzy_search.py:22-38), spread over the batch; the oracle runs on the host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import fuzz_oracle as O
+    O.lib().orc_set_bitpar(1)
+    idx, score, cnt = last
+    nq = len(queries)
+    pick = sorted({int(i) for i in np.linspace(0, nq - 1, rows)})
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(threads) as ex:
+        exp = list(ex.map(lambda qi: O.topk(O.TOKEN_SET, queries[qi], cps, offs, min_score, k), pick))
+    O.lib().orc_set_bitpar(0)
+    bad = [qi for qi, e in zip(pick, exp)
+           if [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] != e]
+    return {"results_checked": len(pick), "results_equal": not bad, "rows": pick, "rows_differing": bad}
+
+
 def c1_leg(device, threshold, k_app=5):
     """BASELINE.json configs[0] (C1), 'as the app runs it': 1 query x 10^4 names <= 32 chars.  The CPU side
     is the loop of reference src/fuzzy_search.py:22-38 statement for statement over the oracle's
@@ -176,9 +194,13 @@ def main():
                          "auto: rccl, torch if the communicator cannot be made.  At --gpus 1, rccl runs a communicator of size 1")
     args = ap.parse_args()
 
+    # torch FIRST, then the library: PyTorch wheels ship their own HIP runtime, and the loader binds libfuzzyhip to
+    # the copy that is already mapped (tts_amd/_lib.py _RULE: one HIP runtime per process).  torch is the launcher
+    # here (rank / world, barrier, the max-over-ranks reduce -- all over gloo on the host) and the fence's
+    # torch.cuda.synchronize(); the data path, RCCL all-gather included, is the library's.
     import torch
     import torch.distributed as dist
-    from tts_amd import Corpus, merge_topk, synth
+    from tts_amd import Corpus, _lib, merge_topk, synth
     from tts_amd.preprocess import min_score_for_threshold, pack_prepared
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,10 +232,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # one node; the container hostname may not resolve
+        # control plane only: the one data-path collective is the library's ncclAllGather (no second RCCL
+        # communicator inside torch)
+        dist.init_process_group("gloo")
 
     t_setup = time.perf_counter()
     if strong:
@@ -243,11 +265,6 @@ def main():
     q_packed = pack_prepared(queries)
     nq = len(queries)
 
-    keys_dev = gathered = None
-    if world > 1:
-        keys_dev = torch.zeros(nq * k, dtype=torch.int64, device="cuda")
-        gathered = torch.zeros(world * nq * k, dtype=torch.int64, device="cpu" if rehearsal else "cuda")
-
     exch = {"gather_ms": 0.0, "merge_ms": 0.0}
     comm, comm_note = None, None
     if (world > 1 and not rehearsal and args.exchange in ("auto", "rccl")) or (world == 1 and args.exchange == "rccl"):
@@ -258,7 +275,20 @@ def main():
         except FuzzyHipError as e:
             if args.exchange == "rccl":
                 raise
-            comm_note = f"library communicator not made ({e}); torch.distributed carries the exchange"
+            comm_note = f"library communicator not made on rank {rank} ({e}); torch.distributed (gloo) carries the exchange"
+        if world > 1:
+            # every rank takes the same carrier: one flag, reduced over all ranks, before the first step
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm, comm_note = None, "library communicator not made on another rank; torch.distributed (gloo) carries the exchange"
+            if int(ok.item()) == 0 and args.exchange == "rccl":
+                raise SystemExit(comm_note)
+    keys_dev = gathered = None
+    if world > 1 and comm is None:
+        keys_dev = torch.zeros(nq * k, dtype=torch.int64, device="cuda")
+        gathered = torch.zeros(world * nq * k, dtype=torch.int64, device="cpu")
 
     def step():
         if comm is not None:
@@ -269,8 +299,8 @@ def main():
             return corpus.topk(q_packed, min_score, k)
         corpus.topk_keys_device(q_packed, min_score, k, keys_dev.data_ptr(), 0, sync=True)
         t1 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, keys_dev.cpu() if rehearsal else keys_dev)
-        host = gathered.cpu().numpy().view(np.uint64)
+        dist.all_gather_into_tensor(gathered, keys_dev.cpu())
+        host = gathered.numpy().view(np.uint64)
         t2 = time.perf_counter()
         out = merge_topk(host, world, nq, k)
         exch["gather_ms"] += (t2 - t1) * 1e3
@@ -290,8 +320,9 @@ def main():
     exch["gather_ms"] = exch["merge_ms"] = 0.0
     fence()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step()
+        last = step()
         t = corpus.timing()
         score_ms += t["score_ms"]; select_ms += t["select_ms"]; prep_ms += t["host_prep_ms"]
         launches += t["score_launches"]
@@ -300,7 +331,7 @@ def main():
     elapsed = time.perf_counter() - t0
     alg_local = float(synth.algorithmic_bytes_per_query(info))
     if world > 1:
-        dev = "cpu" if rehearsal else "cuda"
+        dev = "cpu"
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -385,14 +416,21 @@ def main():
             "fused_chunks_redone_through_matrix": fallback_chunks,
             "setup_seconds": setup_s,
             "source_hash": source_hash(),
+            "runtime": _lib.runtime_paths(),      # the HIP runtime the library is bound to, the librccl it opened
         }
+        if world > 1:
+            # the honest denominator of "x times 1 GPU": the SAME workload on one GPU, measured once and committed
+            one = load_json("c3_1gpu_current.json")
+            if one and (one.get("queries"), one.get("candidates_total"), one.get("k")) == (nq, n_all, k):
+                out["value_1gpu_same_workload"] = one["value"]
+                out["value_1gpu_source"] = one.get("source")
         if world > 1 or comm is not None:
             if comm is not None:
                 out["exchange"] = {"carrier": "libfuzzyhip: ncclAllGather (RCCL) on the corpus' stream + fz_merge_gathered on the device",
                                    "bytes_per_rank_per_step": nq * k * 8,
                                    "all_gather_plus_device_merge_ms_per_step": exch["gather_ms"] / steps}
             else:
-                out["exchange"] = {"carrier": "torch.distributed all_gather_into_tensor + fz_merge_topk on the host",
+                out["exchange"] = {"carrier": "keys to the host, torch.distributed all_gather_into_tensor over gloo, fz_merge_topk on the host",
                                    "bytes_per_rank_per_step": nq * k * 8, "all_gather_ms_per_step": exch["gather_ms"] / steps,
                                    "host_merge_ms_per_step": exch["merge_ms"] / steps}
                 if comm_note:
@@ -410,6 +448,9 @@ def main():
         comm.close()
     corpus.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if last is not None and float(n_local) * args.max_chars <= 2.6e8:
+            # the oracle as checker of what the timed region returned (after the timed region, never inside it)
+            out.update(verify_rows(last, cps, offs, queries, min_score, k, rows=8 if float(n_local) * args.max_chars <= 1.3e8 else 2))
         out["cpu_baseline"] = cpu_baseline(cps, offs, queries, min_score, k)
         c1 = c1_leg(local_rank, args.threshold)
         out["cpu_baseline"]["python_loop"] = c1["python_loop"]

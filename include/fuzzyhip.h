@@ -133,8 +133,21 @@ int fz_corpus_info(const fz_corpus *c, fz_info *out);
 int fz_corpus_save(fz_corpus *c, const char *path);
 int fz_corpus_load(const char *path, int device, uint64_t base_index, fz_corpus **out);
 
-/* run later kernels on the caller's hipStream_t (NULL = the corpus' own stream) */
+/*
+ * run later kernels on the caller's hipStream_t (NULL = the corpus' own stream).
+ * ONE HIP RUNTIME PER PROCESS: the stream must come from the very libamdhip64 this library is bound to
+ * (fz_runtime_paths names it).  PyTorch wheels ship their own copy of libamdhip64 / libhsa-runtime64 / librccl;
+ * a process that loads this library first and torch afterwards maps BOTH runtimes, the second one finds no
+ * device, and a stream or device pointer of one is meaningless to the other.  Rule: import torch BEFORE this
+ * library is loaded (the dynamic loader then binds this library to torch's runtime by its SONAME), or keep
+ * torch out of the process.  tts_amd/_lib.py checks /proc/self/maps at load time and wherever a foreign
+ * stream or pointer comes in, and raises with both paths named.
+ */
 int fz_set_stream(fz_corpus *c, void *hip_stream);
+
+/* path of the HIP runtime this library is bound to, and of the librccl it opened ("" before the first
+ * fz_comm_* call); NUL-terminated, truncated to the capacities given.  No counterpart in the reference. */
+int fz_runtime_paths(char *hip_out, size_t hip_cap, char *rccl_out, size_t rccl_cap);
 
 /* bound on the device workspace the score matrix may take (bytes; default 4 GiB) */
 int fz_set_workspace_limit(fz_corpus *c, uint64_t bytes);
@@ -220,7 +233,14 @@ int fz_merge_topk(const uint64_t *keys, uint32_t n_lists, uint32_t nq, uint32_t 
  * right behind the top-k kernels, followed by a device merge of the n_ranks lists of every query
  * (descending key = score desc, global index asc: identical on every rank and for every n_ranks).  No
  * counterpart in the reference (single process).  librccl is opened with dlopen at the first fz_comm_*
- * call (FUZZYHIP_RCCL_LIB names another file), so single-GPU users never load it.
+ * call, so single-GPU users never load it: FUZZYHIP_RCCL_LIB if set, else the librccl that sits NEXT TO the
+ * libamdhip64 this library is bound to (so that RCCL and the library call the same HIP runtime), else the
+ * loader's default search.
+ * The local top-k is only enqueued: no host synchronisation stands between it and the all-gather.  Each rank
+ * sends one status word behind its keys; a rank whose local step fails still enters the collective (zeroed
+ * keys, status 1) and every rank then returns an error instead of waiting for ever; a fused list that
+ * overflowed (status 2) makes every rank go round once more with that rank's keys redone.  Exchange buffers for
+ * 131 072 keys per rank are reserved by fz_comm_create; larger batches grow them on first use.
  *
  *   fz_comm_unique_id  rank 0 only: FZ_COMM_ID_BYTES bytes to hand to every rank by whatever launched the
  *                      processes (torch.distributed broadcast, a file, MPI, ...)

@@ -3,7 +3,10 @@ librccl per process): the sharded entry point fz_query_topk_sharded against the 
 
     python tests/comm_case.py threads   ranks = threads of this process sharing GPU 0, FUZZYHIP_RCCL_LIB must
                                         name tests/fake_rccl/libfake_rccl.so (2 and 3 ranks)
-    python tests/comm_case.py real      one rank, the real librccl (communicator of size 1)"""
+    python tests/comm_case.py real      one rank, the real librccl (communicator of size 1)
+    python tests/comm_case.py threads_fused   as `threads`, on shards of >= 256 tiles with FUZZYHIP_FUSED_MIN_MB=0
+                                        in the environment: every local top-k takes the fused path (asserted);
+                                        expected results come from a score-matrix corpus (FUZZYHIP_NO_FUSED=1)"""
 import os
 import sys
 import threading
@@ -16,8 +19,8 @@ from tts_amd import Corpus, _lib, synth  # noqa: E402
 from tts_amd.sharded import LibraryExchange, shard_bounds  # noqa: E402
 
 
-def corpus_and_queries():
-    cps, offs = synth.make_corpus(6000, max_chars=64, seed=91, vocab_size=300)
+def corpus_and_queries(n=6000):
+    cps, offs = synth.make_corpus(n, max_chars=64, seed=91, vocab_size=300)
     names = synth.to_strings(cps, offs)
     queries = synth.make_queries(cps, offs, 12, seed=92) + [names[5].split()[0], names[77], "zz qq", ""]
     return names, queries
@@ -35,7 +38,7 @@ def same(a, b):
     return all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-def run_threads(n_ranks, names, queries, cases, exp):
+def run_threads(n_ranks, names, queries, cases, exp, want_fused=False):
     box, ready = {}, threading.Event()
 
     def share(my_id):
@@ -56,6 +59,8 @@ def run_threads(n_ranks, names, queries, cases, exp):
                 for case in cases:
                     sc, ms, k = case
                     results[(rank, case)] = shard.topk_sharded(comm.handle, queries, ms, k, sc)
+                    if want_fused:
+                        assert shard.timing()["fused"] == 1, (rank, case, shard.timing())
                 comm.close()
         except Exception as e:          # noqa: BLE001 -- reported by the main thread
             errors.append((rank, repr(e)))
@@ -74,8 +79,18 @@ def run_threads(n_ranks, names, queries, cases, exp):
 
 def main():
     mode = sys.argv[1]
-    names, queries = corpus_and_queries()
     cases = [(_lib.TOKEN_SET, 35, 10), (_lib.TOKEN_SET, 0, 64), (_lib.RATIO, 50, 7), (_lib.TOKEN_SET, 100, 5)]
+    if mode == "threads_fused":
+        assert "fake_rccl" in os.environ.get("FUZZYHIP_RCCL_LIB", "") and os.environ.get("FUZZYHIP_FUSED_MIN_MB") == "0"
+        names, queries = corpus_and_queries(3 * 17_000)
+        os.environ["FUZZYHIP_NO_FUSED"] = "1"              # read when a corpus is created
+        exp = expected(names, queries, cases)
+        del os.environ["FUZZYHIP_NO_FUSED"]
+        for n_ranks in (2, 3):
+            run_threads(n_ranks, names, queries, cases, exp, want_fused=True)
+        print("comm case ok:", mode)
+        return
+    names, queries = corpus_and_queries()
     exp = expected(names, queries, cases)
     if mode == "threads":
         assert "fake_rccl" in os.environ.get("FUZZYHIP_RCCL_LIB", "")

@@ -165,32 +165,12 @@ def test_full_size_properties():
     assert (mi == idx[:len(queries)]).all() and (ms == score[:len(queries)]).all()
 
 
-def _sharded_worker(rank, world, port, ret):
-    import os, sys
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from tts_amd.sharded import ShardedFuzzySearch
-    cps, offs = synth.make_corpus(4001, max_chars=48, seed=21, vocab_size=40)
-    items = [s.upper() if i % 3 == 0 else s for i, s in enumerate(synth.to_strings(cps, offs))]
-    queries = synth.make_queries(cps, offs, 9, seed=22, max_chars=48)
-    fs = ShardedFuzzySearch(items, items[:50], threshold=0.35, device=0)
-    got = fs.find_best_matches_many(queries, "product")
-    single = FuzzySearch(items, items[:50], threshold=0.35)
-    exp = single.find_best_matches_many(queries, "product")
-    ret[rank] = (got == exp)
-    fs.close(); single.close()
-    dist.destroy_process_group()
-
-
 def test_sharded_two_ranks_one_gpu():
-    """2 ranks sharing the one GPU, gloo for the exchange: sharded result == single-shard result."""
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ret = mp.Manager().dict()
-    mp.spawn(_sharded_worker, args=(2, port, ret), nprocs=2, join=True)
-    assert ret[0] and ret[1]
+    """2 ranks sharing the one GPU, gloo for the exchange (ShardedFuzzySearch exchange="torch", keys handed over
+    as a torch tensor's data_ptr): sharded result == single-shard result.  Ranks are processes of their own
+    (tests/dist_case.py), torch imported first there."""
+    from test_dist_gloo import run_ranks
+    run_ranks("sharded_gpu", 2, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
 
 
 def test_packed_corpus_file_roundtrip(oracle, tmp_path):
@@ -226,18 +206,11 @@ def test_packed_corpus_file_roundtrip(oracle, tmp_path):
 def test_workspace_chunking_and_caller_stream(oracle):
     """A tiny workspace limit forces many query chunks; a caller-provided stream carries the work:
     results must not change."""
-    # a stream of the caller's own, made with the HIP runtime the library itself is linked to (torch ships a
-    # second copy of the runtime; initialising that one late in a process that already works on the GPU
-    # failed now and then on the test box with hipErrorNoDevice, which says nothing about the library)
+    # a stream of the caller's own, made with the very HIP runtime the library is bound to (fz_runtime_paths).
+    # A torch stream is the other legitimate source and is covered by tests/test_gpu_runtime.py, in processes
+    # that import torch first: one HIP runtime per process (tts_amd/_lib.py _RULE).
     import ctypes
-    hip = None
-    for name in ("libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"):
-        try:
-            hip = ctypes.CDLL(name)
-            break
-        except OSError:
-            continue
-    assert hip is not None, "no HIP runtime to make a stream with"
+    hip = ctypes.CDLL(_lib.runtime_paths()["hip"])
     st = ctypes.c_void_p()
     assert hip.hipStreamCreate(ctypes.byref(st)) == 0
     cps, offs = synth.make_corpus(20_000, max_chars=64, seed=101)

@@ -137,6 +137,7 @@ class Corpus:
                          scorer: int = _lib.TOKEN_SET, sync: bool = True) -> int:
         """Per-shard top-k as packed keys written to DEVICE memory (for the RCCL all-gather)."""
         q_cps, q_offs, nq = self._pack_queries(queries)
+        _lib.assert_single_runtime("Corpus.topk_keys_device (a device pointer made by other code)")
         _lib.check(self._lib.fz_query_topk_keys(self._handle(), _u32(q_cps), _u64(q_offs), nq,
                                                 int(scorer), int(min_score), int(k),
                                                 ctypes.c_void_p(keys_ptr),
@@ -173,6 +174,10 @@ class Corpus:
         return {name: getattr(t, name) for name, _ in t._fields_}
 
     def set_stream(self, stream_ptr: Optional[int]) -> None:
+        """Later kernels run on the caller's hipStream_t (None: the corpus' own).  The stream must belong to the HIP
+        runtime the library is bound to: with torch in the process, torch must have been imported first (_lib._RULE)."""
+        if stream_ptr:
+            _lib.assert_single_runtime("Corpus.set_stream")
         _lib.check(self._lib.fz_set_stream(self._handle(), ctypes.c_void_p(stream_ptr or 0)))
 
     def set_workspace_limit(self, nbytes: int) -> None:

@@ -216,6 +216,12 @@ struct fz_corpus {
     uint32_t stream_max_group = 256;                      // most queries one work item takes (FUZZYHIP_STREAM_MAX_GROUP)
     std::vector<hipEvent_t> events;
     fz_timing timing{};
+    // events of an asynchronous call whose kernel times are read once its caller has synchronised (fz_query_topk_sharded)
+    struct Pending {
+        bool valid = false;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> score, select;
+        hipEvent_t first = nullptr, last = nullptr;
+    } pending;
     std::mutex mu;
 };
 
@@ -1297,6 +1303,11 @@ enum RunMode { RUN_TOPK_HOST, RUN_TOPK_DEVICE, RUN_SCORE_ALL, RUN_DIST_ALL };
 struct RunOut {
     uint64_t *idx = nullptr; int32_t *score = nullptr; uint32_t *cnt = nullptr;     // TOPK_HOST
     uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr; int sync = 1;           // TOPK_DEVICE
+    // TOPK_DEVICE without sync: a device word that is 0 after the call's kernels unless a fused list overflowed (then
+    // 2: the keys are not final and the caller redoes the call with force_matrix or sync).  Null: an asynchronous
+    // call never takes the fused path, because nobody could be told about an overflow.
+    uint64_t *d_status = nullptr;
+    int force_matrix = 0;
     uint32_t flat = 0;                         // FZ_ORDER_BY_INDEX: every passing candidate ties
     uint8_t *scores = nullptr;                                                      // SCORE_ALL
     uint16_t *dists = nullptr;                                                      // DIST_ALL
@@ -1675,6 +1686,8 @@ static int run_matrix(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_off
 // each row's limit -> the other tiles append the keys that reach it -> fz_merge_lists.  No score matrix
 // over the whole shard, so a batch is not cut to fit one.  A chunk whose lists overflowed is redone
 // through run_matrix at the end (results identical either way).
+hipError_t fz_launch_fold_status(const uint32_t *ovf, uint32_t n, uint64_t *status, hipStream_t st);
+
 static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                      int view_kind, int kmode, FzTies ties, const TopkTarget &t, RunMode mode, RunOut &o,
                      CallEvents &ev, hipStream_t st)
@@ -1740,6 +1753,11 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
         c->timing.select_launches += 2;
         c->timing.pairs += (uint64_t)rows * c->n;
     }
+    if (mode == RUN_TOPK_DEVICE && !o.sync) {
+        // asynchronous caller: no host look at the counters; they are folded into its status word on the stream
+        HIP_TRY(fz_launch_fold_status(d_ovf, nchunks, o.d_status, st));
+        return FZ_OK;
+    }
     // lists that overflowed (an adversarial order of arrival; none in any workload measured): redo those chunks
     std::vector<uint32_t> h_ovf(nchunks, 0u);
     HIP_TRY(hipStreamSynchronize(st));
@@ -1772,6 +1790,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     if ((rc = build_view(c, view_kind)) != FZ_OK) return rc;
     const View &v = c->views[view_kind];
     hipStream_t st = c->stream;
+    if (mode == RUN_TOPK_DEVICE && !o.sync && o.d_status) HIP_TRY(hipMemsetAsync(o.d_status, 0, 8, st));
     struct WsSwitch {                                    // the corpus works in `fixed_ws` for this call only
         fz_corpus *c; Workspace *prev;
         WsSwitch(fz_corpus *c_, Workspace *f) : c(c_), prev(c_->ws) { if (f) c->ws = f; }
@@ -1779,6 +1798,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     } ws_switch(c, fixed_ws);
     Workspace &w = *c->ws;
     c->timing = fz_timing{};
+    c->pending.valid = false;
 
     const bool nothing = topk && (k == 0 || c->n == 0 || min_score > 100);
     uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr;
@@ -1810,8 +1830,8 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     const TopkTarget t{d_keys, d_cnt, min_score, k, o.flat};
     // fused threshold + top-k when the view keeps a sample in front (large shards), the order is by score,
     // and k is small enough for the lists; the score matrix otherwise
-    const bool fused = topk && c->use_fused && !o.flat && k <= FZ_FUSED_MAX_K && v.n_sample_tiles < v.ntiles &&
-                       (uint64_t)nq * v.npad >= c->fused_min_bytes && (mode == RUN_TOPK_HOST || o.sync);
+    const bool fused = topk && c->use_fused && !o.force_matrix && !o.flat && k <= FZ_FUSED_MAX_K && v.n_sample_tiles < v.ntiles &&
+                       (uint64_t)nq * v.npad >= c->fused_min_bytes && (mode == RUN_TOPK_HOST || o.sync || o.d_status);
     if (fused && getenv("FUZZYHIP_TRACE")) fprintf(stderr, "fuzzyhip: fused top-k over %u rows (%u of %u tiles sampled)\n", nq, v.n_sample_tiles, v.ntiles);
     if (fused) rc = run_fused(c, q_cps, q_offs, nq, view_kind, kmode, ties, t, mode, o, ev, st);
     else rc = run_matrix(c, q_cps, q_offs, 0, nq, view_kind, kmode, ties, mode, o, t, ev, st);
@@ -1825,7 +1845,14 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
         HIP_TRY(hipStreamSynchronize(st));
         decode_keys(c->h_keys, nq, k, o.idx, o.score, o.cnt);
     } else {
-        if (mode == RUN_TOPK_DEVICE && !o.sync) return FZ_OK;       // timings are not collected on the async path
+        if (mode == RUN_TOPK_DEVICE && !o.sync) {
+            // the kernel times are read by finish_pending_timing() once the caller has synchronised the stream
+            if (!w.fixed && (rc = ev.mark(&ev_last, st)) == FZ_OK) {
+                c->pending.valid = true; c->pending.score = ev.score; c->pending.select = ev.select;
+                c->pending.first = ev_first; c->pending.last = ev_last;
+            }
+            return FZ_OK;
+        }
         if ((rc = ev.mark(&ev_last, st)) != FZ_OK) return rc;
         HIP_TRY(hipStreamSynchronize(st));
     }
@@ -1833,6 +1860,16 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     for (auto &s : ev.select) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.select_ms += ms; }
     { float ms = 0; if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) c->timing.total_ms = ms; }
     return FZ_OK;
+}
+
+// kernel times of the last asynchronous call (its stream must have been synchronised since); c->mu held
+static void finish_pending_timing(fz_corpus *c)
+{
+    if (!c->pending.valid) return;
+    for (auto &s : c->pending.score) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.score_ms += ms; }
+    for (auto &s : c->pending.select) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.select_ms += ms; }
+    { float ms = 0; if (hipEventElapsedTime(&ms, c->pending.first, c->pending.last) == hipSuccess) c->timing.total_ms = ms; }
+    c->pending.valid = false;
 }
 
 static int fz_query_topk_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
@@ -2084,17 +2121,37 @@ struct Api {
 static Api g_api;
 static std::mutex g_api_mu;
 
+// directory of the HIP runtime THIS library is bound to (the object that defines hipGetDeviceCount for us).
+// A process may map a second copy (PyTorch wheels ship their own libamdhip64 / libhsa-runtime64 / librccl): RCCL
+// must be the one built against the runtime we call, so it is looked for next to that runtime first.
+static std::string hip_runtime_path()
+{
+    Dl_info di;
+    if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &di) && di.dli_fname) return di.dli_fname;
+    return "";
+}
+
+static std::string g_rccl_path;
+
 static int load()
 {
     std::lock_guard<std::mutex> lk(g_api_mu);
     if (g_api.handle) return FZ_OK;
-    const char *names[3] = {getenv("FUZZYHIP_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+    std::vector<std::string> names;
+    if (const char *e = getenv("FUZZYHIP_RCCL_LIB")) if (*e) names.push_back(e);
+    const std::string hip = hip_runtime_path();
+    const size_t slash = hip.rfind('/');
+    if (slash != std::string::npos) {
+        names.push_back(hip.substr(0, slash + 1) + "librccl.so.1");
+        names.push_back(hip.substr(0, slash + 1) + "librccl.so");
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
     void *h = nullptr;
     std::string tried;
-    for (const char *nm : names) {
-        if (!nm || !*nm) continue;
-        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+    for (const std::string &nm : names) {
+        h = dlopen(nm.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (h) { g_rccl_path = nm; break; }
         const char *e = dlerror();
         tried += std::string(tried.empty() ? "" : "; ") + nm + ": " + (e ? e : "?");
     }
@@ -2108,6 +2165,10 @@ static int load()
     if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather || !a.get_error_string) {
         dlclose(h);
         return fail(FZ_ERR_COMM, "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString");
+    }
+    {
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void *>(a.all_gather), &di) && di.dli_fname) g_rccl_path = di.dli_fname;
     }
     g_api = a;
     return FZ_OK;
@@ -2124,8 +2185,10 @@ struct fz_comm {
     rccl::Comm comm = nullptr;
     int n_ranks = 1, rank = 0, device = 0;
     std::mutex mu;
+    // per rank and call: nq*k keys + one status word (0 ok, 1 the rank's local step failed, 2 a fused list overflowed)
     uint64_t *d_local = nullptr, *d_all = nullptr, *d_out = nullptr, *h_out = nullptr;
     size_t local_cap = 0, all_cap = 0, out_cap = 0, h_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~fz_comm()
     {
         if (hipSetDevice(device) != hipSuccess) return;
@@ -2134,8 +2197,34 @@ struct fz_comm {
         if (d_all) (void)hipFree(d_all);
         if (d_out) (void)hipFree(d_out);
         if (h_out) (void)hipHostFree(h_out);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
     }
 };
+
+// exchange buffers for `words` u64 per rank; grown outside the steady state only (fz_comm_create reserves
+// FZ_COMM_RESERVE_WORDS, enough for 10^4 queries x top-10)
+#define FZ_COMM_RESERVE_WORDS (131072u + 1u)
+static int comm_reserve(fz_comm *cm, size_t words)
+{
+    auto grow = [&](uint64_t **p, size_t *cap, size_t need) -> int {
+        if (need <= *cap) return FZ_OK;
+        if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), need * 8));
+        *cap = need;
+        return FZ_OK;
+    };
+    int rc;
+    if ((rc = grow(&cm->d_local, &cm->local_cap, words)) != FZ_OK) return rc;
+    if ((rc = grow(&cm->d_all, &cm->all_cap, words * (size_t)cm->n_ranks)) != FZ_OK) return rc;
+    if ((rc = grow(&cm->d_out, &cm->out_cap, words)) != FZ_OK) return rc;
+    if (words + 1 > cm->h_cap) {
+        if (cm->h_out) { HIP_TRY(hipHostFree(cm->h_out)); cm->h_out = nullptr; cm->h_cap = 0; }
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&cm->h_out), (words + 1) * 8, hipHostMallocDefault));
+        cm->h_cap = words + 1;
+    }
+    return FZ_OK;
+}
 
 static int fz_comm_unique_id_impl(void *id_out)
 {
@@ -2164,12 +2253,25 @@ static int fz_comm_create_impl(const void *id, int n_ranks, int rank, int device
     rccl::UniqueId uid;
     memcpy(uid.internal, id, FZ_COMM_ID_BYTES);
     RCCL_TRY(rccl::g_api.comm_init_rank(&cm->comm, n_ranks, uid, rank));
+    HIP_TRY(hipEventCreate(&cm->ev0));
+    HIP_TRY(hipEventCreate(&cm->ev1));
+    if ((rc = comm_reserve(cm.get(), FZ_COMM_RESERVE_WORDS)) != FZ_OK) return rc;
     *out = cm.release();
     return FZ_OK;
 }
 
 // Local top-k keys -> all-gather on the corpus' stream -> device merge of the n_ranks lists per query ->
 // one copy of nq*k keys to the host.  Every rank ends up with the same, global, result.
+//
+// The local step is only ENQUEUED (no host synchronisation in front of the collective), and every rank enters
+// the collective whatever happened to its local step: a status word travels behind each rank's keys (0 ok, 1
+// the local step failed -- its keys are zeroed --, 2 a fused list overflowed, so the keys are not final).  After
+// the one synchronisation at the end every rank knows the worst status: on 1 all ranks return an error (the
+// failing rank its own), on 2 all ranks go round once more, the overflowed ones with their local step redone
+// synchronously (which repairs overflowed chunks through the score matrix), the others with the keys they have.
+hipError_t fz_launch_merge_gathered_strided(const uint64_t *all, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
+                                            uint64_t *out, uint64_t *status_out, hipStream_t st);
+
 static int fz_query_topk_sharded_impl(fz_corpus *c, fz_comm *cm, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                                      int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx, int32_t *out_score,
                                      uint32_t *out_cnt)
@@ -2185,38 +2287,51 @@ static int fz_query_topk_sharded_impl(fz_corpus *c, fz_comm *cm, const uint32_t 
         if (out_cnt && nq) memset(out_cnt, 0, (size_t)nq * 4);
         return FZ_OK;
     }
+    int view, kmode; FzTies ties; int rc;
+    // argument errors are the same on every rank (same queries, scorer, k): returning here leaves no peer waiting
+    if ((rc = scorer_plan(scorer & 0xFF, &view, &kmode, &ties)) != FZ_OK) return rc;
     std::lock_guard<std::mutex> lk(cm->mu);
     HIP_TRY(hipSetDevice(cm->device));
-    const size_t nkeys = (size_t)nq * k;
-    auto grow = [&](uint64_t **p, size_t *cap, size_t need) -> int {
-        if (need <= *cap) return FZ_OK;
-        if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), need * 8));
-        *cap = need;
-        return FZ_OK;
-    };
-    int rc;
-    if ((rc = grow(&cm->d_local, &cm->local_cap, nkeys)) != FZ_OK) return rc;
-    if ((rc = grow(&cm->d_all, &cm->all_cap, nkeys * (size_t)cm->n_ranks)) != FZ_OK) return rc;
-    if ((rc = grow(&cm->d_out, &cm->out_cap, nkeys)) != FZ_OK) return rc;
-    if (nkeys > cm->h_cap) {
-        if (cm->h_out) { HIP_TRY(hipHostFree(cm->h_out)); cm->h_out = nullptr; cm->h_cap = 0; }
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&cm->h_out), nkeys * 8, hipHostMallocDefault));
-        cm->h_cap = nkeys;
+    const size_t nkeys = (size_t)nq * k, words = nkeys + 1;
+    if ((rc = comm_reserve(cm, words)) != FZ_OK) return rc;         // grows only beyond what fz_comm_create reserved
+    uint64_t *d_status = cm->d_local + nkeys;
+    float exchange_ms = 0.f;
+    bool redo_sync = false;
+    for (int round = 0; round < 2; ++round) {
+        int local_rc = FZ_OK;
+        std::string local_err;
+        if (round == 0 || redo_sync) {
+            RunOut o; o.d_keys = cm->d_local; o.d_cnt = nullptr; o.sync = redo_sync ? 1 : 0; o.d_status = d_status;
+            o.flat = (scorer & FZ_ORDER_BY_INDEX) ? 1u : 0u;
+            local_rc = run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_DEVICE, o);
+            if (local_rc != FZ_OK) local_err = g_err;
+        }
+        std::lock_guard<std::mutex> lc(c->mu);                      // the corpus' stream and timing record
+        hipStream_t st = c->stream;
+        if (local_rc != FZ_OK) {
+            // still enter the collective, with no keys and status 1: the peers must not wait for this rank for ever
+            HIP_TRY(hipMemsetAsync(cm->d_local, 0, words * 8, st));
+            HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_status), 1, 1, st));
+        } else if (round == 1) {
+            HIP_TRY(hipMemsetAsync(d_status, 0, 8, st));            // keys are final now (redone, or never in doubt)
+        }
+        HIP_TRY(hipEventRecord(cm->ev0, st));
+        RCCL_TRY(rccl::g_api.all_gather(cm->d_local, cm->d_all, words, rccl::kUint64, cm->comm, st));
+        HIP_TRY(fz_launch_merge_gathered_strided(cm->d_all, words, (uint32_t)cm->n_ranks, nq, k, cm->d_out, cm->d_out + nkeys, st));
+        HIP_TRY(hipEventRecord(cm->ev1, st));
+        HIP_TRY(hipMemcpyAsync(cm->h_out, cm->d_out, words * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cm->h_out + words, d_status, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        { float ms = 0; if (hipEventElapsedTime(&ms, cm->ev0, cm->ev1) == hipSuccess) exchange_ms += ms; }
+        if (round == 0) finish_pending_timing(c);
+        c->timing.exchange_ms = exchange_ms;
+        const uint64_t worst = cm->h_out[nkeys], mine = cm->h_out[words];
+        if (local_rc != FZ_OK) return fail(local_rc, "%s", local_err.c_str());
+        if (worst == 1ull) return fail(FZ_ERR_COMM, "another rank failed in its local top-k step (its own call returns the cause); no result");
+        if (worst == 0ull) break;
+        if (round == 1) return fail(FZ_ERR_COMM, "a rank reported unfinished keys twice");
+        redo_sync = mine == 2ull;                                   // worst == 2: one more round, on every rank
     }
-    // the local shard: keys on the device, rows padded with 0 (complete when the call returns)
-    if ((rc = fz_query_topk_keys_impl(c, q_cps, q_offs, nq, scorer, min_score, k, cm->d_local, nullptr, 1)) != FZ_OK) return rc;
-    std::lock_guard<std::mutex> lc(c->mu);                          // the corpus' stream and timing record
-    hipStream_t st = c->stream;
-    hipEvent_t e0 = get_event(c, 0), e1 = get_event(c, 1);
-    if (!e0 || !e1) return fail(FZ_ERR_HIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(e0, st));
-    RCCL_TRY(rccl::g_api.all_gather(cm->d_local, cm->d_all, nkeys, rccl::kUint64, cm->comm, st));
-    HIP_TRY(fz_launch_merge_gathered(cm->d_all, (uint32_t)cm->n_ranks, nq, k, cm->d_out, st));
-    HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipMemcpyAsync(cm->h_out, cm->d_out, nkeys * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    { float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->timing.exchange_ms = ms; }
     decode_keys(cm->h_out, nq, k, out_idx, out_score, out_cnt);
     return FZ_OK;
 }
@@ -2295,6 +2410,19 @@ extern "C" int fz_distance_batch(int device, int kind, const uint32_t *a_cps, co
                                  uint32_t *out_dist)
 {
     return guarded([&] { return fz_distance_batch_impl(device, kind, a_cps, a_offs, b_cps, b_offs, n_pairs, out_dist); });
+}
+
+// Which HIP runtime this library is bound to, and which librccl it opened ("" before the first fz_comm_* call).
+extern "C" int fz_runtime_paths(char *hip_out, size_t hip_cap, char *rccl_out, size_t rccl_cap)
+{
+    return guarded([&] {
+        const std::string hip = rccl::hip_runtime_path();
+        std::string rc;
+        { std::lock_guard<std::mutex> lk(rccl::g_api_mu); rc = rccl::g_rccl_path; }
+        if (hip_out && hip_cap) { snprintf(hip_out, hip_cap, "%s", hip.c_str()); }
+        if (rccl_out && rccl_cap) { snprintf(rccl_out, rccl_cap, "%s", rc.c_str()); }
+        return (int)FZ_OK;
+    });
 }
 
 extern "C" int fz_comm_unique_id(void *id_out)

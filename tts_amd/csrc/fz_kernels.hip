@@ -1618,8 +1618,11 @@ __global__ __launch_bounds__(256) void fz_merge_lists(FzMergeParams p)
 // ---------------------------------------------------------------------------------------------
 // sharded path: the gathered key lists [n_lists][nq][k] of a query -> its global top-k (descending key)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fz_merge_gathered(const uint64_t *__restrict__ all, uint32_t n_lists, uint32_t nq,
-                                                         uint32_t k, uint64_t *__restrict__ out)
+// list l of rank-major gathered data starts at all + l * list_stride (nq*k keys, then words the merge ignores).
+// status_out (optional): the largest of the words all[l * list_stride + nq*k], l = 0 .. n_lists-1 -- the status
+// each rank sends behind its keys (fz_query_topk_sharded)
+__global__ __launch_bounds__(256) void fz_merge_gathered(const uint64_t *__restrict__ all, uint64_t list_stride, uint32_t n_lists, uint32_t nq,
+                                                         uint32_t k, uint64_t *__restrict__ out, uint64_t *__restrict__ status_out)
 {
     extern __shared__ __align__(16) uint64_t s_mg[];
     const uint32_t tid = threadIdx.x, row = blockIdx.x;
@@ -1628,15 +1631,24 @@ __global__ __launch_bounds__(256) void fz_merge_gathered(const uint64_t *__restr
     while (P < total) P <<= 1;
     for (uint32_t i = tid; i < P; i += blockDim.x) {
         uint64_t v = 0ull;                                  // padding sorts last: a real key is never 0
-        if (i < total) v = all[((uint64_t)(i / k) * nq + row) * k + (i % k)];
+        if (i < total) v = all[(uint64_t)(i / k) * list_stride + (uint64_t)row * k + (i % k)];
         s_mg[i] = v;
     }
     __syncthreads();
     fz_bitonic<uint64_t, true>(s_mg, P);
     for (uint32_t i = tid; i < k; i += blockDim.x) out[(uint64_t)row * k + i] = s_mg[i];
+    if (status_out != nullptr && row == 0u && tid == 0u) {
+        uint64_t worst = 0ull;
+        for (uint32_t l = 0; l < n_lists; ++l) {
+            const uint64_t v = all[(uint64_t)l * list_stride + (uint64_t)nq * k];
+            if (v > worst) worst = v;
+        }
+        *status_out = worst;
+    }
 }
 
-hipError_t fz_launch_merge_gathered(const uint64_t *all, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t *out, hipStream_t st)
+hipError_t fz_launch_merge_gathered_strided(const uint64_t *all, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
+                                            uint64_t *out, uint64_t *status_out, hipStream_t st)
 {
     if (nq == 0u || k == 0u || n_lists == 0u) return hipSuccess;
     if ((uint64_t)n_lists * k > FZ_COMM_MAX_MERGE) return hipErrorInvalidValue;
@@ -1647,7 +1659,28 @@ hipError_t fz_launch_merge_gathered(const uint64_t *all, uint32_t n_lists, uint3
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_merge_gathered), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(fz_merge_gathered, dim3(nq), dim3(256), lds, st, all, n_lists, nq, k, out);
+    hipLaunchKernelGGL(fz_merge_gathered, dim3(nq), dim3(256), lds, st, all, list_stride, n_lists, nq, k, out, status_out);
+    return hipGetLastError();
+}
+
+hipError_t fz_launch_merge_gathered(const uint64_t *all, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t *out, hipStream_t st)
+{
+    return fz_launch_merge_gathered_strided(all, (uint64_t)nq * k, n_lists, nq, k, out, nullptr, st);
+}
+
+// status word of an asynchronous fused call: 2 when any chunk's overflow counter is non-zero (the word was
+// cleared on the stream before the call's kernels)
+__global__ __launch_bounds__(64) void fz_fold_status(const uint32_t *__restrict__ ovf, uint32_t n, uint64_t *__restrict__ status)
+{
+    bool any = false;
+    for (uint32_t i = threadIdx.x; i < n; i += 64u) any |= ovf[i] != 0u;
+    if (__ballot(any) != 0ull && threadIdx.x == 0u) *status = 2ull;
+}
+
+hipError_t fz_launch_fold_status(const uint32_t *ovf, uint32_t n, uint64_t *status, hipStream_t st)
+{
+    if (status == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fz_fold_status, dim3(1), dim3(64), 0, st, ovf, n, status);
     return hipGetLastError();
 }
 

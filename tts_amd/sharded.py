@@ -7,8 +7,8 @@ merge (descending packed key = score desc, global index asc), so 1/2/4/8-GPU res
 construction.  The reference has no counterpart (it is single-process).
 
 Two carriers of that step:
-  exchange="rccl"   inside the library (``LibraryExchange``): ``ncclAllGather`` on the corpus' stream and a
-                    device merge kernel; torch is only the launcher that hands the 128-byte communicator
+  exchange="rccl"   (default) inside the library (``LibraryExchange``): ``ncclAllGather`` on the corpus' stream and
+                    a device merge kernel; torch is only the launcher that hands the 128-byte communicator
                     id to the ranks (or no torch at all: ``comm_id_via_file``)
   exchange="torch"  ``torch.distributed.all_gather_into_tensor`` + the host merge ``fz_merge_topk`` (also
                     what the gloo tests on the CPU run)"""
@@ -89,6 +89,7 @@ class LibraryExchange:
 
     def __init__(self, rank: int, world: int, device: int, share: Callable[[Optional[bytes]], bytes]):
         self._lib = _lib.load()
+        _lib.assert_single_runtime("LibraryExchange")
         self.rank, self.world, self.device = rank, world, device
         self._h = ctypes.c_void_p()
         my_id = None
@@ -131,10 +132,12 @@ class ShardedFuzzySearch:
 
     def __init__(self, products: List[str], customers: List[str],
                  threshold: float = FUZZY_SEARCH_THRESHOLD_FLOAT, *, device: Optional[int] = None,
-                 top_n: Optional[int] = None, exchange: str = "torch", comm: Optional[LibraryExchange] = None):
-        """exchange="rccl": the all-gather and the merge run inside the library; pass `comm` (a
-        LibraryExchange made by the launcher) to keep torch out of the process altogether, otherwise the id
-        is broadcast once over the default torch.distributed group.  exchange="torch": module docstring."""
+                 top_n: Optional[int] = None, exchange: str = "rccl", comm: Optional[LibraryExchange] = None):
+        """exchange="rccl" (default, the exchange BASELINE.json's north_star names): the all-gather and the merge
+        run inside the library; pass `comm` (a LibraryExchange made by the launcher, e.g. with comm_id_via_file) to
+        keep torch out of the process altogether, otherwise the id is broadcast once over the default
+        torch.distributed group (any backend; gloo will do: no torch.cuda call is made here).
+        exchange="torch": module docstring.  `device` defaults to LOCAL_RANK."""
         if exchange not in ("torch", "rccl"):
             raise ValueError("exchange must be 'torch' or 'rccl'")
         self.products, self.customers, self.threshold = products, customers, threshold
@@ -145,10 +148,9 @@ class ShardedFuzzySearch:
             self._rank, self._world = comm.rank, comm.world
             self._device = comm.device if device is None else device
         else:
-            import torch
             import torch.distributed as dist
             self._rank, self._world = dist.get_rank(), dist.get_world_size()
-            self._device = torch.cuda.current_device() if device is None else device
+            self._device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
             if exchange == "rccl":
                 self._comm = LibraryExchange(self._rank, self._world, self._device, comm_id_via_torch())
         self._corpora = {}
@@ -168,6 +170,7 @@ class ShardedFuzzySearch:
             idx, score, cnt = corpus.topk_sharded(self._comm.handle, prepared, min_score_for_threshold(self.threshold), k)
             return [[(items[int(idx[q, j])], int(score[q, j]) / 100.0) for j in range(int(cnt[q]))] for q in range(nq)]
         import torch
+        _lib.assert_single_runtime("ShardedFuzzySearch(exchange='torch')")     # a torch tensor's pointer goes to the library
         keys = torch.zeros(nq * k, dtype=torch.int64, device=torch.device("cuda", self._device))
         corpus.topk_keys_device(prepared, min_score_for_threshold(self.threshold), k, keys.data_ptr(), 0,
                                 _lib.TOKEN_SET, sync=True)
