@@ -118,10 +118,12 @@ _RULE = ("one HIP runtime per process: PyTorch wheels ship their own libamdhip64
 
 
 def assert_single_runtime(where: str) -> None:
-    """Raise when two copies of the HIP or HSA runtime are mapped (see _RULE); called when the library is loaded and
-    wherever a stream or device pointer made by other code comes in (set_stream, torch tensors, communicators)."""
+    """Raise when two copies of the HIP runtime are mapped (see _RULE); called when the library is loaded and
+    wherever a stream or device pointer made by other code comes in (set_stream, torch tensors, communicators).
+    A second libhsa-runtime64 alone is not an error: rocprofv3 maps /opt/rocm's copy into every process it
+    profiles, and a copy no HIP runtime initialises is inert (mapped_runtimes() still lists it)."""
     rt = mapped_runtimes()
-    for k in ("libamdhip64", "libhsa-runtime64"):
+    for k in ("libamdhip64",):
         if len(rt[k]) > 1:
             raise FuzzyHipError(f"{where}: two copies of {k} are mapped in this process ({' and '.join(rt[k])}); {_RULE}")
 

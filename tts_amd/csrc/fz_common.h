@@ -128,7 +128,7 @@ struct FzStreamParams {
     const FzTile *tiles;
     const uint32_t *tile_list; // indices of the eligible tiles
     uint32_t ntiles;           // entries of tile_list
-    uint32_t nwaves;           // waves per block = tiles per block
+    uint32_t nwaves;           // waves per block (1..8): they share the block's ONE unit and split the item's queries
     uint32_t stride;           // dwords per lane of one Peq table word plane (odd, > max row)
     uint32_t nq;               // queries of this launch
     uint32_t q_per_block;      // queries per group
@@ -137,7 +137,7 @@ struct FzStreamParams {
     uint32_t slab_units;       // units per slab: a slab's symbols, ids and ends stay cache resident while every
                                // query group passes over it (a shard larger than the Infinity Cache is otherwise
                                // re-streamed from HBM once per group)
-    uint32_t grid_blocks;      // persistent blocks to launch (the chip's CU count x blocks per CU)
+    uint32_t grid_blocks;      // persistent blocks to launch (the chip's CU count x blocks a CU holds at 8 waves per SIMD)
     uint32_t chunk;            // items a wave draws at a time (1..64)
     uint32_t *work_counter;    // FZ_STREAM_QUEUES device counters FZ_STREAM_QPAD words apart, zero before the launch
     const uint8_t *row_of_sym; // [256] corpus symbol -> 4 * row, 0xFF = no query of this launch uses it

@@ -37,7 +37,7 @@ int fz_pick_width(uint32_t m);
 size_t fz_score_lds_bytes(int W, const FzScoreParams &p);
 hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq, hipStream_t st);
 hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st);
-size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves);
+size_t fz_stream_lds_bytes(int W, int stride);
 hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_t st);
 hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st);
 hipError_t fz_launch_combine(const FzCombineParams &p, uint32_t rows, hipStream_t st);
@@ -212,8 +212,8 @@ struct fz_corpus {
     uint64_t slab_bytes = 24ull << 20;                    // FUZZYHIP_SLAB_KB: corpus bytes one stream kernel keeps cache resident
     uint32_t stream_oversub = 1;                          // FUZZYHIP_STREAM_OVERSUB: persistent blocks per slot
     uint32_t pipe_chunks = 1;                             // FUZZYHIP_CHUNKS: pieces of a large top-k batch
-    uint32_t stream_waves = 16, stream_blocks = 1536;     // tuning knobs (FUZZYHIP_STREAM_WAVES / _BLOCKS)
-    uint32_t stream_max_group = 256;                      // most queries one work item takes (FUZZYHIP_STREAM_MAX_GROUP)
+    uint32_t stream_waves = 0, stream_blocks = 192;       // tuning knobs (FUZZYHIP_STREAM_WAVES: waves per block, 0 = by kernel; _BLOCKS)
+    uint32_t stream_max_group = 1024;                     // most queries one work item takes (FUZZYHIP_STREAM_MAX_GROUP); its waves share them out
     std::vector<hipEvent_t> events;
     fz_timing timing{};
     // events of an asynchronous call whose kernel times are read once its caller has synchronised (fz_query_topk_sharded)
@@ -1525,12 +1525,15 @@ static int launch_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, cons
             p.sym = v.d_sym; p.tokid = v.d_tokid; p.tokend = v.d_tokend; p.tiles = v.d_tiles;
             p.tile_list = lists[cls];
             p.ntiles = nt; p.stride = stride;
-            p.nwaves = 16;
-            while (p.nwaves > 1 && fz_stream_lds_bytes(W, (int)stride, p.nwaves) > 160 * 1024) --p.nwaves;
-            p.nwaves = std::min<uint32_t>(p.nwaves, std::max<uint32_t>(1, c->stream_waves));
+            // G = 4 waves share one unit's LDS column and split the item's queries (fz_kernels.hip, "work queues").  One
+            // pattern word: 64 registers, 8 blocks = 32 waves per CU; two words: 96 registers and a 19 KB column, 5 blocks
+            p.nwaves = std::min<uint32_t>(8u, std::max<uint32_t>(1u, c->stream_waves ? c->stream_waves : 4u));
+            const size_t lds_b = fz_stream_lds_bytes(W, (int)stride);
+            const uint32_t waves_per_cu = W == 2 ? 20u : 32u;
+            const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds_b, waves_per_cu / p.nwaves));
             p.nq = (uint32_t)b.qrec.size();
             // enough blocks to balance the chip, enough queries per block to amortise the tile set-up
-            const uint64_t bx = (units + p.nwaves - 1) / p.nwaves;
+            const uint64_t bx = (units + 15u) / 16u;
             uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (c->stream_blocks + bx - 1) / bx));
             // ... and no item so long that the launch ends in a tail of it (a large batch over a large shard)
             by = std::max<uint64_t>(by, (p.nq + c->stream_max_group - 1) / c->stream_max_group);
@@ -1540,13 +1543,11 @@ static int launch_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, cons
             p.nitems = (uint32_t)((uint64_t)units * groups);
             // slabs: every query group passes over one cache-sized run of units before the next run is touched
             p.slab_units = (uint32_t)std::min<uint64_t>(units, std::max<uint64_t>(1, c->slab_bytes / (tile_bytes * (cls == 0 ? 2u : 1u))));
-            // as many persistent blocks as fit the chip at this LDS size; each drains the work queue
-            const size_t lds_b = fz_stream_lds_bytes(W, (int)stride, p.nwaves);
-            p.grid_blocks = c->n_cus * (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_b) * c->stream_oversub;
+            // as many persistent blocks as the chip holds at this LDS size and 8 waves per SIMD; each drains the work queues
+            p.grid_blocks = c->n_cus * blocks_per_cu * c->stream_oversub;
             // small items (few queries per group) are drawn several at a time, but never so many that
-            // the chip's waves cannot all get a share
-            const uint64_t waves_total = (uint64_t)p.grid_blocks * p.nwaves;
-            p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1u, 32u / p.q_per_block), p.nitems / waves_total));
+            // the chip's blocks cannot all get a share
+            p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1u, 32u / p.q_per_block), p.nitems / p.grid_blocks));
             p.work_counter = w.d_counters + (size_t)(c->counter_next++ % FZ_COUNTER_SLOTS) * FZ_STREAM_QUEUES * FZ_STREAM_QPAD;
             HIP_TRY(hipMemsetAsync(p.work_counter, 0, FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), lst));
             p.row_of_sym = w.d_qbuf + P.o_rows;

@@ -639,11 +639,10 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
                                                   uint32_t col_off, const uint32_t (&cid)[FZ_STREAM_MAX_TOK],
                                                   const uint32_t (&Rm)[FZ_STREAM_MAX_TOK][W],
                                                   const uint32_t (&psep)[W], uint32_t clen, uint32_t out_off,
-                                                  uint32_t orig, uint32_t qgroup)
+                                                  uint32_t orig, uint32_t q0, uint32_t q1)
 {
     constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;
-    uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
-    if (q1 > p.nq) q1 = p.nq;
+    if (q0 >= q1) return;
     // ONE record is in flight: a consumer copies what it needs of `cur` and then asks for the next record
     // (no cur = nxt rotation of two records: fewer scalar moves, and measured 1.5 % faster; the scalar
     // cache answers quickly enough that a deeper prefetch buys nothing).  The stream ends with padding records.
@@ -707,7 +706,7 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
             // record are in flight before its first step: the empty asm pins them there, and its memory
             // clobber keeps the next record's scalar load BELOW the wait, so that the load overlaps this
             // record's steps instead of being waited for at once.
-            uint32_t row[12][W];
+            uint32_t row[8][W];
 #define FZ_ROWS4(g, word) do { const uint32_t o_[4] = {fz_add_byte<0>((word), col_off), fz_add_byte<1>((word), col_off), fz_add_byte<2>((word), col_off), fz_add_byte<3>((word), col_off)}; \
                                _Pragma("unroll") for (int k = 0; k < 4; ++k) _Pragma("unroll") for (int w = 0; w < W; ++w) row[4 * (g) + k][w] = fz_lds_load(o_[k] + (uint32_t)w * PLANE); } while (0)
 #define FZ_PIN4(g) do { _Pragma("unroll") for (int k = 0; k < 4; ++k) _Pragma("unroll") for (int w = 0; w < W; ++w) asm volatile("" : "+v"(row[4 * (g) + k][w]) : : "memory"); } while (0)
@@ -722,9 +721,13 @@ __device__ __forceinline__ void fz_stream_queries(const FzStreamParams &p, const
                 FZ_ADVANCE();
                 FZ_STEPS4(0); FZ_STEPS4(1);
             } else {
-                FZ_ROWS4(0, s0); FZ_ROWS4(1, s1); FZ_ROWS4(2, s2); FZ_PIN4(0); FZ_PIN4(1); FZ_PIN4(2);
+                // 9 to 12 symbols (rare): eight rows in flight, then the last four into the first slots again
+                // (twelve at once cost the registers that keep 8 waves per SIMD from fitting)
+                FZ_ROWS4(0, s0); FZ_ROWS4(1, s1); FZ_PIN4(0); FZ_PIN4(1);
                 FZ_ADVANCE();
-                FZ_STEPS4(0); FZ_STEPS4(1); FZ_STEPS4(2);
+                FZ_STEPS4(0); FZ_STEPS4(1);
+                FZ_ROWS4(0, s2); FZ_PIN4(0);
+                FZ_STEPS4(0);
             }
 #undef FZ_ROWS4
 #undef FZ_PIN4
@@ -779,76 +782,110 @@ __device__ __forceinline__ void fz_item_decode(uint32_t item, uint32_t units, ui
     unit = first + (r - qgroup * size);
 }
 
+// ---- work queues ----------------------------------------------------------------------------------------
+// One BLOCK of G waves owns one unit (a tile, or a pair of tiles) at a time: the unit's match masks live in ONE
+// LDS column set that all G waves read, and the queries of the item are cut into G runs, one per wave.  Sharing
+// the column is what lets 8 waves per SIMD run: a column is 9.5 KB (19 KB with two pattern words), so a wave
+// with a column of its own leaves room for 4 (2) waves per SIMD, where one wave issues an instruction every ~7
+// cycles and the SIMD idles in between (tools/valu_rate.hip: 1.9 cycles per plain VALU instruction at 4 waves
+// per SIMD, 1.4 at 8; measured on this kernel with a timing-only build: score phase 3.27 -> 2.65 ms).
+// Items are (query group, unit) pairs numbered slab-major and dealt round-robin to FZ_STREAM_QUEUES queues, each
+// behind its own counter (one counter for the whole chip serialises at ~12 ns per draw); wave 0 of a block draws
+// `chunk` positions at a time from its home queue and moves on to the next queue when that one is empty.  Exit:
+// counters only grow, and a block leaves when a scan finds every queue drained (every wave of the block sees
+// the same end marker behind the same barrier).
+struct FzDraw { uint32_t queue, pos, pos_end; };
+
+// next item of this block, or 0xFFFFFFFF when every queue is drained; called by ONE whole wave (all 64 lanes)
+__device__ __forceinline__ uint32_t fz_draw_item(const FzStreamParams &p, FzDraw &d, uint32_t lane)
+{
+    for (;;) {
+        if (d.pos < d.pos_end) {
+            const uint32_t item = d.queue + d.pos * FZ_STREAM_QUEUES;
+            ++d.pos;
+            return item;
+        }
+        // queue q holds the items q, q + QUEUES, q + 2*QUEUES, ...: all queues walk the query groups
+        // in the same order, so the chip works on the same records at the same time (scalar cache)
+        const uint32_t q_len = d.queue < p.nitems ? (p.nitems - d.queue + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES : 0u;
+        // counters sit FZ_STREAM_QPAD words apart (one cache line each); a plain load first, so
+        // that a drained queue costs no atomic
+        uint32_t *cnt = p.work_counter + d.queue * FZ_STREAM_QPAD;
+        uint32_t got = 0xFFFFFFFFu;
+        if (lane == 0u && q_len != 0u && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_len)
+            got = atomicAdd(cnt, p.chunk);
+        got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+        if (got >= q_len) {
+            // this queue is drained: lane l looks at queue l, the wave moves to the next queue that
+            // still has positions, or reports the end when there is none (one load round trip, not QUEUES)
+            bool open = false;
+            if (lane < FZ_STREAM_QUEUES && lane < p.nitems) {
+                const uint32_t len_l = (p.nitems - lane + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES;
+                open = __hip_atomic_load(p.work_counter + lane * FZ_STREAM_QPAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len_l;
+            }
+            const uint64_t mask = __ballot(open);
+            if (mask == 0ull) return 0xFFFFFFFFu;
+            const uint64_t ahead = mask >> d.queue;                    // queues at or after this one
+            d.queue = ahead != 0ull ? d.queue + (uint32_t)__builtin_ctzll(ahead) : (uint32_t)__builtin_ctzll(mask);
+            continue;
+        }
+        d.pos = got;
+        d.pos_end = got + p.chunk < q_len ? got + p.chunk : q_len;
+    }
+}
+
+// the run of queries wave `wave` of `nw` takes out of group `qgroup`
+__device__ __forceinline__ void fz_wave_queries(const FzStreamParams &p, uint32_t qgroup, uint32_t wave, uint32_t nw,
+                                                uint32_t &q0, uint32_t &q1)
+{
+    uint32_t g0 = qgroup * p.q_per_block, g1 = g0 + p.q_per_block;
+    if (g1 > p.nq) g1 = p.nq;
+    const uint32_t per = (g1 - g0 + nw - 1u) / nw;
+    q0 = g0 + wave * per;
+    q1 = q0 + per < g1 ? q0 + per : g1;
+}
+
 template <int W, int MODE, int STRIDE, bool EMIT>
-__global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const FzRec *__restrict__ recs,
-                                                        uint8_t *__restrict__ scores)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 5, 8)))      // two pattern words: 96 registers, 5 waves per SIMD
+void fz_score_stream(FzStreamParams p, const FzRec *__restrict__ recs, uint8_t *__restrict__ scores)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     uint8_t *s_tab = reinterpret_cast<uint8_t *>(lds);                   // [128][64] rounded ratios T[L][d >> 1]
     uint8_t *s_row = s_tab + FZ_STREAM_TAB_BYTES;                        // [256] symbol -> 4 * row
-    uint8_t *s_peq = s_row + 256u;                                       // [nwaves][W][64][STRIDE] u32
+    uint8_t *s_peq = s_row + 256u;                                       // [W][64][STRIDE] u32: the block's ONE column set
     constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;              // bytes of one word plane
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_peq + (uint32_t)W * PLANE);   // [0]: the block's current item
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t nw = blockDim.x >> 6;
     for (uint32_t i = tid; i < FZ_STREAM_TAB_BYTES / 16u; i += blockDim.x)
         reinterpret_cast<uint4 *>(s_tab)[i] = reinterpret_cast<const uint4 *>(p.score_tab)[i];
     if (tid < 64u) reinterpret_cast<uint32_t *>(s_row)[tid] = reinterpret_cast<const uint32_t *>(p.row_of_sym)[tid];
-    __syncthreads();                                                     // the only block-wide barrier
 
-    // ---- work queues: every wave takes (query group, tile) items until none is left ---------------
-    // A wave that finishes early takes the next item instead of idling until its block is done: the
-    // LDS column is private to the wave, so no block-wide barrier is needed after the table load
-    // above.  Items are numbered group-major and dealt round-robin to FZ_STREAM_QUEUES queues, each
-    // behind its own counter (one counter for the whole chip serialises at ~12 ns per draw); a wave
-    // draws `chunk` positions at a time from its home queue and moves on to the next queue when that
-    // one is empty.  Exit: counters only grow, and a wave leaves when a scan finds every queue drained.
-    uint8_t *col = s_peq + wave * ((uint32_t)W * PLANE) + lane * ((uint32_t)STRIDE * 4u);   // this lane's column
+    uint8_t *col = s_peq + lane * ((uint32_t)STRIDE * 4u);               // this lane's column (shared by the block's waves)
     const uint32_t col_off = fz_lds_addr(col);
-    uint32_t queue = (blockIdx.x + wave) % FZ_STREAM_QUEUES;
-    uint32_t pos = 0u, pos_end = 0u;                     // positions [pos, pos_end) of `queue` are this wave's
+    FzDraw draw{blockIdx.x % FZ_STREAM_QUEUES, 0u, 0u};
     for (;;) {
-        if (pos >= pos_end) {
-            // queue q holds the items q, q + QUEUES, q + 2*QUEUES, ...: all queues walk the query groups
-            // in the same order, so the chip works on the same records at the same time (scalar cache)
-            const uint32_t q_len = queue < p.nitems ? (p.nitems - queue + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES : 0u;
-            // counters sit FZ_STREAM_QPAD words apart (one cache line each); a plain load first, so
-            // that a drained queue costs no atomic
-            uint32_t *cnt = p.work_counter + queue * FZ_STREAM_QPAD;
-            uint32_t got = 0xFFFFFFFFu;
-            if (lane == 0u && q_len != 0u && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_len)
-                got = atomicAdd(cnt, p.chunk);
-            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            if (got >= q_len) {
-                // this queue is drained: lane l looks at queue l, the wave moves to the next queue that
-                // still has positions, or leaves when there is none (one load round trip, not QUEUES)
-                bool open = false;
-                if (lane < FZ_STREAM_QUEUES && lane < p.nitems) {
-                    const uint32_t len_l = (p.nitems - lane + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES;
-                    open = __hip_atomic_load(p.work_counter + lane * FZ_STREAM_QPAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len_l;
-                }
-                const uint64_t mask = __ballot(open);
-                if (mask == 0ull) break;
-                const uint64_t ahead = mask >> queue;                    // queues at or after this one
-                queue = ahead != 0ull ? queue + (uint32_t)__builtin_ctzll(ahead) : (uint32_t)__builtin_ctzll(mask);
-                continue;
-            }
-            pos = got;
-            pos_end = got + p.chunk < q_len ? got + p.chunk : q_len;
+        __syncthreads();                                 // every wave is done with the column and with s_ctl
+        if (wave == 0u) {
+            const uint32_t it = fz_draw_item(p, draw, lane);
+            if (lane == 0u) s_ctl[0] = it;
         }
-        const uint32_t item = queue + pos * FZ_STREAM_QUEUES;
-        ++pos;
+        // the column starts from zero: wave w clears the rows w, w + nw, ...
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            for (uint32_t r = wave; r < (uint32_t)STRIDE; r += nw) *reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r * 4u) = 0u;
+        __syncthreads();                                 // the item is known, the column is clear
+        const uint32_t item = s_ctl[0];
+        if (item == 0xFFFFFFFFu) break;
         uint32_t qgroup, tix;
         fz_item_decode(item, p.ntiles, p.slab_units, (p.nq + p.q_per_block - 1u) / p.q_per_block, qgroup, tix);
         const uint32_t tile = p.tile_list[tix];
         const FzTile td = p.tiles[tile];
         const uint32_t ndw = td.ndw, ntok = td.ntok;
 
-        // ---- candidate side, once per item -------------------------------------------------------
-#pragma unroll
-        for (int w = 0; w < W; ++w)
-            for (uint32_t r = 0; r < (uint32_t)STRIDE; ++r) *reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r * 4u) = 0u;
-
+        // ---- candidate side, once per item (lane constants in every wave; the LDS writes are shared out) ----
         uint32_t cid[FZ_STREAM_MAX_TOK], Rm[FZ_STREAM_MAX_TOK][W], prev_end = 0u;
 #pragma unroll
         for (int i = 0; i < (int)FZ_STREAM_MAX_TOK; ++i) {
@@ -874,6 +911,7 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
         for (int d = 0; d < 8 * W; ++d) {
             if ((uint32_t)d < ndw) {
                 const uint32_t cw = p.sym[td.coff + (uint32_t)d * 64u + lane];
+                const bool mine = ((uint32_t)d % nw) == wave;                // this wave writes dword d's match bits
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t s = (cw >> (8 * k)) & 0xFFu;
@@ -881,7 +919,7 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
                     const int w = (d * 4 + k) >> 5;
                     if (MODE == FZ_MODE_TOKEN_SET && s == FZ_SYM_SPACE) {
                         psep[w] |= bit;
-                    } else {
+                    } else if (mine) {
                         const uint32_t r4 = s_row[s];                        // 0xFF: no query uses this symbol
                         if (r4 != 0xFFu)
                             __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r4), bit,
@@ -890,16 +928,19 @@ __global__ __launch_bounds__(1024) void fz_score_stream(FzStreamParams p, const 
                 }
             }
         }
+        __syncthreads();                                 // the column is complete
 
-        // ---- the queries of this group: a stream of wave-uniform records (scalar loads) ------------
+        // ---- this wave's run of the group's queries: a stream of wave-uniform records (scalar loads) ----
+        uint32_t q0, q1;
+        fz_wave_queries(p, qgroup, wave, nw, q0, q1);
         const uint32_t out_off = tile * 64u + lane;
         const uint32_t orig = EMIT ? p.emit.orig_of_phys[out_off] : 0u;
-        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
-        else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
-        else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
-        else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
-        else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
-        else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, qgroup);
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries<W, MODE, STRIDE, 1, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, q0, q1);
+        else if (ntok == 2u) fz_stream_queries<W, MODE, STRIDE, 2, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, q0, q1);
+        else if (ntok == 3u) fz_stream_queries<W, MODE, STRIDE, 3, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, q0, q1);
+        else if (ntok == 4u) fz_stream_queries<W, MODE, STRIDE, 4, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, q0, q1);
+        else if (ntok == 5u) fz_stream_queries<W, MODE, STRIDE, 5, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, q0, q1);
+        else fz_stream_queries<W, MODE, STRIDE, (int)FZ_STREAM_MAX_TOK, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, orig, q0, q1);
     }
 }
 
@@ -922,8 +963,9 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
                                                      const uint32_t (&Rm)[2][FZ_PK_MAX_TOK], uint32_t psep,
                                                      const uint32_t (&clen)[2], const uint32_t (&out_off)[2],
                                                      const uint32_t (&fmask)[2], const uint32_t (&fw)[2], uint32_t negstop,
-                                                     const uint32_t (&orig)[2], uint32_t qgroup)
+                                                     const uint32_t (&orig)[2], uint32_t q0, uint32_t q1)
 {
+    if (q0 >= q1) return;
     // Lane constants of the score look-ups (end of the query loop).  With bm = popcount(M & field) and
     // bv = popcount(V & field): sect1 = fw - bm, lcs = fw - bv, and (m + clen) >> 1 = (m >> 1) + (clen >> 1)
     // + (m & clen & 1), so every table index is a per-tile lane constant + a per-query scalar + popcounts.
@@ -941,8 +983,6 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
 #pragma unroll
         for (int i = 0; i < NT; ++i) nRm[h][i] = ~Rm[h][i];
     }
-    uint32_t q0 = qgroup * p.q_per_block, q1 = q0 + p.q_per_block;
-    if (q1 > p.nq) q1 = p.nq;
     // ONE record is in flight: a consumer copies what it needs of `cur` and then asks for the next record
     // (no cur = nxt rotation of two records: fewer scalar moves, and measured 1.5 % faster; the scalar
     // cache answers quickly enough that a deeper prefetch buys nothing).  The stream ends with padding records.
@@ -999,7 +1039,7 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
 #define FZ_MK() do { if (MODE == FZ_MODE_TOKEN_SET) { const uint32_t pos_ = (meta >> 8) & 31u; \
                          const uint32_t tA = fz_bit_spread(has >> 1, pos_), tB = fz_bit_spread(has, pos_); \
                          Mk = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(M, tA, fm[0], 0x70), tB, fm[1], 0x70); } } while (0)
-            uint32_t row[12];
+            uint32_t row[8];
 #define FZ_ROWS4(g, word) do { const uint32_t o_[4] = {fz_add_byte<0>((word), col_off), fz_add_byte<1>((word), col_off), fz_add_byte<2>((word), col_off), fz_add_byte<3>((word), col_off)}; \
                                _Pragma("unroll") for (int k = 0; k < 4; ++k) row[4 * (g) + k] = fz_lds_load(o_[k]); } while (0)
 #define FZ_PIN4(g) do { _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(row[4 * (g) + k]) : : "memory"); } while (0)
@@ -1015,9 +1055,12 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
                 FZ_ADVANCE();
                 FZ_STEPS4(0); FZ_STEPS4(1);
             } else {
-                FZ_ROWS4(0, s0); FZ_ROWS4(1, s1); FZ_ROWS4(2, s2); FZ_MK(); FZ_PIN4(0); FZ_PIN4(1); FZ_PIN4(2);
+                // 9 to 12 symbols (rare): eight rows in flight, then the last four into the first slots again
+                FZ_ROWS4(0, s0); FZ_ROWS4(1, s1); FZ_MK(); FZ_PIN4(0); FZ_PIN4(1);
                 FZ_ADVANCE();
-                FZ_STEPS4(0); FZ_STEPS4(1); FZ_STEPS4(2);
+                FZ_STEPS4(0); FZ_STEPS4(1);
+                FZ_ROWS4(0, s2); FZ_PIN4(0);
+                FZ_STEPS4(0);
             }
             if (MODE == FZ_MODE_TOKEN_SET && (meta & 8u)) FZ_PK_STEP(psep);
 #undef FZ_MK
@@ -1070,58 +1113,42 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
 }
 
 template <int MODE, int STRIDE, bool EMIT>
-__global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, const FzRec *__restrict__ recs,
-                                                           uint8_t *__restrict__ scores)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void fz_score_stream_pk(FzStreamParams p, const FzRec *__restrict__ recs, uint8_t *__restrict__ scores)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     uint8_t *s_tab = reinterpret_cast<uint8_t *>(lds);                   // [128][64] rounded ratios T[L][d >> 1]
     uint8_t *s_row = s_tab + FZ_STREAM_TAB_BYTES;                        // [256] symbol -> 4 * row
-    uint8_t *s_peq = s_row + 256u;                                       // [nwaves][64][STRIDE] u32
+    uint8_t *s_peq = s_row + 256u;                                       // [64][STRIDE] u32: the block's ONE column set
     constexpr uint32_t PLANE = 64u * (uint32_t)STRIDE * 4u;
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(s_peq + PLANE);       // [0]: the block's current item
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t nw = blockDim.x >> 6;
     for (uint32_t i = tid; i < FZ_STREAM_TAB_BYTES / 16u; i += blockDim.x)
         reinterpret_cast<uint4 *>(s_tab)[i] = reinterpret_cast<const uint4 *>(p.score_tab)[i];
     if (tid < 64u) reinterpret_cast<uint32_t *>(s_row)[tid] = reinterpret_cast<const uint32_t *>(p.row_of_sym)[tid];
     if (fz_lds_addr(s_tab) & (FZ_STREAM_TAB_BYTES - 1u)) __builtin_trap();    // fz_tab_load ORs indices onto this address
-    __syncthreads();                                                     // the only block-wide barrier
 
-    uint8_t *col = s_peq + wave * PLANE + lane * ((uint32_t)STRIDE * 4u);   // this lane's column
+    uint8_t *col = s_peq + lane * ((uint32_t)STRIDE * 4u);               // this lane's column (shared by the block's waves)
     const uint32_t col_off = fz_lds_addr(col);
     const uint32_t npairs = (p.ntiles + 1u) / 2u;                        // an item = (query group, pair of tiles)
-    uint32_t queue = (blockIdx.x + wave) % FZ_STREAM_QUEUES;
-    uint32_t pos = 0u, pos_end = 0u;
-    for (;;) {
-        if (pos >= pos_end) {                                            // same queue protocol as fz_score_stream
-            const uint32_t q_len = queue < p.nitems ? (p.nitems - queue + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES : 0u;
-            uint32_t *cnt = p.work_counter + queue * FZ_STREAM_QPAD;
-            uint32_t got = 0xFFFFFFFFu;
-            if (lane == 0u && q_len != 0u && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_len)
-                got = atomicAdd(cnt, p.chunk);
-            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            if (got >= q_len) {
-                bool open = false;
-                if (lane < FZ_STREAM_QUEUES && lane < p.nitems) {
-                    const uint32_t len_l = (p.nitems - lane + FZ_STREAM_QUEUES - 1u) / FZ_STREAM_QUEUES;
-                    open = __hip_atomic_load(p.work_counter + lane * FZ_STREAM_QPAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len_l;
-                }
-                const uint64_t mask = __ballot(open);
-                if (mask == 0ull) break;
-                const uint64_t ahead = mask >> queue;
-                queue = ahead != 0ull ? queue + (uint32_t)__builtin_ctzll(ahead) : (uint32_t)__builtin_ctzll(mask);
-                continue;
-            }
-            pos = got;
-            pos_end = got + p.chunk < q_len ? got + p.chunk : q_len;
+    FzDraw draw{blockIdx.x % FZ_STREAM_QUEUES, 0u, 0u};
+    for (;;) {                                                           // same block protocol as fz_score_stream
+        __syncthreads();
+        if (wave == 0u) {
+            const uint32_t it = fz_draw_item(p, draw, lane);
+            if (lane == 0u) s_ctl[0] = it;
         }
-        const uint32_t item = queue + pos * FZ_STREAM_QUEUES;
-        ++pos;
+        for (uint32_t r = wave; r < (uint32_t)STRIDE; r += nw) *reinterpret_cast<uint32_t *>(col + r * 4u) = 0u;
+        __syncthreads();
+        const uint32_t item = s_ctl[0];
+        if (item == 0xFFFFFFFFu) break;
         uint32_t qgroup, pair;
         fz_item_decode(item, npairs, p.slab_units, (p.nq + p.q_per_block - 1u) / p.q_per_block, qgroup, pair);
 
         // ---- candidate side: two tiles, once per item --------------------------------------------
-        for (uint32_t r = 0; r < (uint32_t)STRIDE; ++r) *reinterpret_cast<uint32_t *>(col + r * 4u) = 0u;
         uint32_t cid[2][FZ_PK_MAX_TOK], Rm[2][FZ_PK_MAX_TOK], clen[2], out_off[2], psep = 0u, ntok = 0u;
         // entry 2*pair carries the split S above the tile index: field A = bits [0, S), B = bits [S + 1, 32)
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.tile_list[2u * pair]);
@@ -1153,6 +1180,7 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
             for (int d = 0; d < 8; ++d) {
                 if ((uint32_t)d < td.ndw) {
                     const uint32_t cw = p.sym[td.coff + (uint32_t)d * 64u + lane];
+                    const bool mine = ((uint32_t)(d + h) % nw) == wave;      // this wave writes the match bits of dword d
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const uint32_t s = (cw >> (8 * k)) & 0xFFu;
@@ -1160,7 +1188,7 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
                             const uint32_t bit = 1u << ((uint32_t)(d * 4 + k) + sh[h]);
                             if (MODE == FZ_MODE_TOKEN_SET && s == FZ_SYM_SPACE) {
                                 psep |= bit;
-                            } else {
+                            } else if (mine) {
                                 const uint32_t r4 = s_row[s];            // 0xFF: no query uses this symbol
                                 if (r4 != 0xFFu)
                                     __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(col + r4), bit,
@@ -1172,31 +1200,35 @@ __global__ __launch_bounds__(1024) void fz_score_stream_pk(FzStreamParams p, con
             }
         }
         ntok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ntok);
+        __syncthreads();                                 // the column is complete
+        uint32_t q0, q1;
+        fz_wave_queries(p, qgroup, wave, nw, q0, q1);
         uint32_t orig[2] = {0u, 0u};
         if (EMIT) { orig[0] = p.emit.orig_of_phys[out_off[0]]; orig[1] = p.emit.orig_of_phys[out_off[1]]; }
-        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, qgroup);
-        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, qgroup);
-        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, qgroup);
-        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, qgroup);
+        if (MODE != FZ_MODE_TOKEN_SET || ntok <= 1u) fz_stream_queries_pk<MODE, STRIDE, 1, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, q0, q1);
+        else if (ntok == 2u) fz_stream_queries_pk<MODE, STRIDE, 2, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, q0, q1);
+        else if (ntok == 3u) fz_stream_queries_pk<MODE, STRIDE, 3, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, q0, q1);
+        else fz_stream_queries_pk<MODE, STRIDE, (int)FZ_PK_MAX_TOK, EMIT>(p, recs, scores, s_tab, col_off, cid, Rm, psep, clen, out_off, fmask, fw, 0u - (1u << S), orig, q0, q1);
     }
 }
 
-size_t fz_stream_lds_bytes(int W, int stride, uint32_t nwaves)
+// LDS of one block: score table, symbol -> row map, ONE column set (shared by the block's waves), control words
+size_t fz_stream_lds_bytes(int W, int stride)
 {
-    return (size_t)FZ_STREAM_TAB_BYTES + 256u + (size_t)nwaves * W * 64u * stride * 4u;
+    return (size_t)FZ_STREAM_TAB_BYTES + 256u + (size_t)W * 64u * stride * 4u + 16u;
 }
 
 template <int W, int MODE, int STRIDE, bool EMIT>
 static hipError_t launch_stream4(const FzStreamParams &p, hipStream_t st)
 {
-    const size_t lds = fz_stream_lds_bytes(W, STRIDE, p.nwaves);
+    const size_t lds = fz_stream_lds_bytes(W, STRIDE);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_stream<W, MODE, STRIDE, EMIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    // persistent blocks (one per CU at full LDS) drain the (query group, tile) work queue
-    const uint64_t blocks_needed = ((uint64_t)p.nitems + p.nwaves - 1u) / p.nwaves;
+    // persistent blocks (as many as a CU holds at this LDS size and 8 waves per SIMD) drain the (query group, tile) work queues
+    const uint64_t blocks_needed = p.nitems;
     dim3 grid((uint32_t)(blocks_needed < p.grid_blocks ? blocks_needed : p.grid_blocks));
     hipLaunchKernelGGL((fz_score_stream<W, MODE, STRIDE, EMIT>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
     return hipGetLastError();
@@ -1221,13 +1253,13 @@ static hipError_t launch_stream2(const FzStreamParams &p, hipStream_t st)
 template <int MODE, int STRIDE, bool EMIT>
 static hipError_t launch_stream_pk3(const FzStreamParams &p, hipStream_t st)
 {
-    const size_t lds = fz_stream_lds_bytes(1, STRIDE, p.nwaves);
+    const size_t lds = fz_stream_lds_bytes(1, STRIDE);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_score_stream_pk<MODE, STRIDE, EMIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const uint64_t blocks_needed = ((uint64_t)p.nitems + p.nwaves - 1u) / p.nwaves;
+    const uint64_t blocks_needed = p.nitems;
     dim3 grid((uint32_t)(blocks_needed < p.grid_blocks ? blocks_needed : p.grid_blocks));
     hipLaunchKernelGGL((fz_score_stream_pk<MODE, STRIDE, EMIT>), grid, dim3(p.nwaves * 64u), lds, st, p, p.recs, p.scores);
     return hipGetLastError();
@@ -1252,7 +1284,7 @@ static hipError_t launch_stream_pk(const FzStreamParams &p, hipStream_t st)
 hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st)
 {
     if (p.nq == 0u || p.ntiles == 0u) return hipSuccess;
-    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u || p.slab_units == 0u) return hipErrorInvalidValue;
+    if (p.nwaves == 0u || p.nwaves > 8u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u || p.slab_units == 0u) return hipErrorInvalidValue;
     if ((p.ntiles & 1u) || (uint64_t)(p.ntiles / 2u) * ((p.nq + p.q_per_block - 1u) / p.q_per_block) != p.nitems) return hipErrorInvalidValue;
     if (mode == FZ_MODE_TOKEN_SET) return launch_stream_pk<FZ_MODE_TOKEN_SET>(p, st);
     if (mode == FZ_MODE_RATIO) return launch_stream_pk<FZ_MODE_RATIO>(p, st);
@@ -1262,7 +1294,7 @@ hipError_t fz_launch_stream_pk(int mode, const FzStreamParams &p, hipStream_t st
 hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_t st)
 {
     if (p.nq == 0u || p.ntiles == 0u) return hipSuccess;
-    if (p.nwaves == 0u || p.nwaves > 16u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u || p.slab_units == 0u) return hipErrorInvalidValue;
+    if (p.nwaves == 0u || p.nwaves > 8u || p.q_per_block == 0u || p.grid_blocks == 0u || !p.work_counter || p.chunk == 0u || p.chunk > 64u || p.slab_units == 0u) return hipErrorInvalidValue;
     if ((uint64_t)p.ntiles * ((p.nq + p.q_per_block - 1u) / p.q_per_block) != p.nitems) return hipErrorInvalidValue;
     if (W == 1 && mode == FZ_MODE_TOKEN_SET) return launch_stream2<1, FZ_MODE_TOKEN_SET>(p, st);
     if (W == 2 && mode == FZ_MODE_TOKEN_SET) return launch_stream2<2, FZ_MODE_TOKEN_SET>(p, st);
