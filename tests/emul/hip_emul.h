@@ -181,6 +181,8 @@ static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetc
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline int __builtin_amdgcn_readfirstlane(int x)    // every live lane of the wave calls it

@@ -157,6 +157,32 @@ def test_topk_under_ties(oracle, runner, tmp_path):
             assert got == exp, (k, ms, q, got[:5], exp[:5])
 
 
+def test_sliced_select_few_rows(oracle, runner, tmp_path):
+    """a few rows over a 'large' shard (FUZZYHIP_SELECT_SLICE=256 makes 700 candidates large): several blocks per row,
+    the last one to finish merges; ties in every run, the walk in original order inside a run, the first-passing order"""
+    env = {"FUZZYHIP_SELECT_SLICE": "256"}
+    cps, offs = synth.make_corpus(700, max_chars=32, seed=18, vocab_size=9)
+    cand = synth.to_strings(cps, offs)
+    queries = synth.make_queries(cps, offs, 5, seed=19, max_chars=32) + [cand[0].split()[0], ""]
+    buf, o = oracle.pack(cand)
+    for k, ms in ((10, 35), (1, 0), (5, 100), (300, 50)):
+        idx, score, cnt = _run(runner, tmp_path, 2, 0, cand, queries, min_score=ms, k=k, env=env)
+        for qi, q in enumerate(queries):
+            exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, ms, k)
+            got = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
+            assert got == exp, (k, ms, q, got[:5], exp[:5])
+    cand2 = ["aa bb"] * 2500 + ["aa"] * 3 + ["cc"] * 20
+    buf2, o2 = oracle.pack(cand2)
+    idx, score, cnt = _run(runner, tmp_path, 2, 0, cand2, ["aa bb", "cc dd"], min_score=35, k=12, env=env)
+    for qi, q in enumerate(["aa bb", "cc dd"]):
+        exp = oracle.topk(oracle.TOKEN_SET, q, buf2, o2, 35, 12)
+        assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == exp
+    idx, score, cnt = _run(runner, tmp_path, 2, 0 | 0x100, cand2, ["aa", "cc"], min_score=100, k=4, env=env)
+    for qi, q in enumerate(["aa", "cc"]):
+        exp = [i for i, s_ in enumerate(cand2) if oracle.score(oracle.TOKEN_SET, q, s_) >= 100][:4]
+        assert [int(idx[qi, j]) for j in range(int(cnt[qi]))] == exp
+
+
 def test_fused_topk_sample_and_lists(oracle, runner, tmp_path):
     """the fused top-k path (sample tiles -> limit per row -> appended lists -> merge) and the slab-major
     item order, forced onto a small corpus: every 2nd tile is a sample tile, slabs of 1 KB; token_set over

@@ -16,7 +16,7 @@
 
 #define REP8(x) x x x x x x x x
 
-enum { K_ADD, K_BITOP3, K_ADD3, K_SDWA, K_STEP1, K_STEP2, K_STEP_PK, K_STEP_PK_BR, K_SALU, K_LOOP_LDS, K_ADD3_V, K_ADD_S, K_STEP_PK_V, K_CMP_OR, K_CNDMASK, K_BFE_I, N_KINDS };
+enum { K_ADD, K_BITOP3, K_ADD3, K_SDWA, K_STEP1, K_STEP2, K_STEP_PK, K_STEP_PK_BR, K_SALU, K_LOOP_LDS, K_ADD3_V, K_ADD_S, K_STEP_PK_V, K_CMP_OR, K_CNDMASK, K_BFE_I, K_LOOP_ADDTID, K_LOOP_ADDTID_NONOP, N_KINDS };
 static const char *kNames[N_KINDS] = {
     "v_add_u32 (4 independent chains)",
     "v_bitop3_b32 (4 independent chains)",
@@ -34,14 +34,16 @@ static const char *kNames[N_KINDS] = {
     "2 x v_cmp_eq_u32 (SGPR-pair results) + s_or_b64 (3 instructions per group)",
     "v_cndmask_b32 with an SGPR-pair mask (4 independent chains)",
     "v_bfe_i32 v, v, 0, 1 + v_lshrrev_b32 (2 per group, dependent)",
+    "stream inner loop with rows [row][lane]: 8 x (s_bfe -> m0, s_nop, ds_read_addtid_b32), wait, 8 dependent packed steps (counted as the 32 instructions of the sdwa form)",
+    "the same without the s_nop between the m0 write and the read (timing only: hazard not honoured)",
 };
-static const int kOpsPerIter[N_KINDS] = {32, 32, 32, 32, 24, 48, 24, 24, 32, 8 * (8 + 8 * 3), 32, 32, 24, 24, 32, 16};
+static const int kOpsPerIter[N_KINDS] = {32, 32, 32, 32, 24, 48, 24, 24, 32, 8 * (8 + 8 * 3), 32, 32, 24, 24, 32, 16, 8 * (8 + 8 * 3), 8 * (8 + 8 * 3)};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *clk, int iters, unsigned sval)
 {
     __shared__ unsigned lds[256 * 17];                         // 17 KB: eight blocks fit one CU
-    if constexpr (KIND == K_LOOP_LDS) {
+    if constexpr (KIND == K_LOOP_LDS || KIND == K_LOOP_ADDTID || KIND == K_LOOP_ADDTID_NONOP) {
         for (int i = threadIdx.x; i < 256 * 17; i += 256) lds[i] = i * 2654435761u;
         __syncthreads();
     }
@@ -102,6 +104,48 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *clk,
                          : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "s"(mk));)
         } else if (KIND == K_BFE_I) {
             REP8(asm volatile("v_bfe_i32 %1, %0, 0, 1\n v_lshrrev_b32 %0, 1, %0\n" : "+v"(a), "+v"(b));)
+        } else if (KIND == K_LOOP_ADDTID || KIND == K_LOOP_ADDTID_NONOP) {
+            // rows stored [row][lane] (256 B per row): the row address is wave-uniform and travels in m0
+            // (ds_read_addtid_b32: address = m0 + offset + 4 * lane), no vector address arithmetic
+            unsigned r0_, r1, r2, r3, r4, r5, r6, r7, t8, t9;
+            const unsigned w0 = ((sval & 0x3Fu) << 8) | (((sval >> 6) & 0x3Fu) << 24), w1 = (((sval >> 3) & 0x3Fu) << 8) | (((sval >> 9) & 0x3Fu) << 24);
+            const unsigned w2 = (((sval >> 5) & 0x3Fu) << 8) | (((sval >> 11) & 0x3Fu) << 24), w3 = (((sval >> 7) & 0x3Fu) << 8) | (((sval >> 13) & 0x3Fu) << 24);
+#define NOPQ(x) x
+            if (KIND == K_LOOP_ADDTID) {
+                REP8(asm volatile(
+                    "s_bfe_u32 m0, %11, 0x100000\n s_nop 0\n ds_read_addtid_b32 %0\n s_bfe_u32 m0, %11, 0x100010\n s_nop 0\n ds_read_addtid_b32 %1\n"
+                    "s_bfe_u32 m0, %12, 0x100000\n s_nop 0\n ds_read_addtid_b32 %2\n s_bfe_u32 m0, %12, 0x100010\n s_nop 0\n ds_read_addtid_b32 %3\n"
+                    "s_bfe_u32 m0, %13, 0x100000\n s_nop 0\n ds_read_addtid_b32 %4\n s_bfe_u32 m0, %13, 0x100010\n s_nop 0\n ds_read_addtid_b32 %5\n"
+                    "s_bfe_u32 m0, %14, 0x100000\n s_nop 0\n ds_read_addtid_b32 %6\n s_bfe_u32 m0, %14, 0x100010\n s_nop 0\n ds_read_addtid_b32 %7\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_bitop3_b32 %8, %10, %0, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %1, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %2, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %3, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %4, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %5, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %6, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %7, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    : "=&v"(r0_), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(t8), "=&v"(t9), "+v"(a)
+                    : "s"(w0), "s"(w1), "s"(w2), "s"(w3), "v"(f), "s"(sval) : "memory", "m0", "scc");)
+            } else {
+                REP8(asm volatile(
+                    "s_bfe_u32 m0, %11, 0x100000\n ds_read_addtid_b32 %0\n s_bfe_u32 m0, %11, 0x100010\n ds_read_addtid_b32 %1\n"
+                    "s_bfe_u32 m0, %12, 0x100000\n ds_read_addtid_b32 %2\n s_bfe_u32 m0, %12, 0x100010\n ds_read_addtid_b32 %3\n"
+                    "s_bfe_u32 m0, %13, 0x100000\n ds_read_addtid_b32 %4\n s_bfe_u32 m0, %13, 0x100010\n ds_read_addtid_b32 %5\n"
+                    "s_bfe_u32 m0, %14, 0x100000\n ds_read_addtid_b32 %6\n s_bfe_u32 m0, %14, 0x100010\n ds_read_addtid_b32 %7\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_bitop3_b32 %8, %10, %0, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %1, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %2, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %3, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %4, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %5, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %6, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    "v_bitop3_b32 %8, %10, %7, %15 bitop3:0x80\n v_add3_u32 %9, %10, %8, %16\n v_bitop3_b32 %10, %9, %10, %8 bitop3:0xf6\n"
+                    : "=&v"(r0_), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(t8), "=&v"(t9), "+v"(a)
+                    : "s"(w0), "s"(w1), "s"(w2), "s"(w3), "v"(f), "s"(sval) : "memory", "m0", "scc");)
+            }
         } else {
             // one "record" of the stream kernels: eight row addresses (column + symbol byte), eight LDS reads,
             // one wait, eight dependent Hyyro steps on the rows read
@@ -141,7 +185,7 @@ struct Result { double ms, cyc_per_instr, ghz, ginstr_per_s; };
 template <int KIND>
 static Result run(int blocks_per_cu, int n_cus)
 {
-    const int blocks = n_cus * blocks_per_cu, iters = KIND == K_LOOP_LDS ? 3000 : 20000;
+    const int blocks = n_cus * blocks_per_cu, iters = (KIND == K_LOOP_LDS || KIND == K_LOOP_ADDTID || KIND == K_LOOP_ADDTID_NONOP) ? 3000 : 20000;
     unsigned *d; unsigned long long *clk;
     if (hipMalloc(&d, (size_t)blocks * 256 * 4) != hipSuccess || hipMalloc(&clk, (size_t)blocks * 16) != hipSuccess) exit(2);
     hipEvent_t e0, e1;
@@ -177,7 +221,7 @@ int main()
     printf("{\"device\": \"%s\", \"cus\": %d, \"simds\": %d, \"unit\": \"wave64 VALU instructions\", \"results\": [\n", prop.gcnArchName, n_cus, n_cus * 4);
     bool first = true;
     for (int w : {1, 2, 4, 8}) {
-        Result (*fns[N_KINDS])(int, int) = {run<K_ADD>, run<K_BITOP3>, run<K_ADD3>, run<K_SDWA>, run<K_STEP1>, run<K_STEP2>, run<K_STEP_PK>, run<K_STEP_PK_BR>, run<K_SALU>, run<K_LOOP_LDS>, run<K_ADD3_V>, run<K_ADD_S>, run<K_STEP_PK_V>, run<K_CMP_OR>, run<K_CNDMASK>, run<K_BFE_I>};
+        Result (*fns[N_KINDS])(int, int) = {run<K_ADD>, run<K_BITOP3>, run<K_ADD3>, run<K_SDWA>, run<K_STEP1>, run<K_STEP2>, run<K_STEP_PK>, run<K_STEP_PK_BR>, run<K_SALU>, run<K_LOOP_LDS>, run<K_ADD3_V>, run<K_ADD_S>, run<K_STEP_PK_V>, run<K_CMP_OR>, run<K_CNDMASK>, run<K_BFE_I>, run<K_LOOP_ADDTID>, run<K_LOOP_ADDTID_NONOP>};
         for (int kind = 0; kind < N_KINDS; ++kind) {
             const Result r = fns[kind](w, n_cus);
             printf("%s  {\"kind\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"clock_ghz\": %.3f, \"cycles_per_instr_per_simd\": %.3f, \"chip_ginstr_per_s\": %.1f}",

@@ -165,6 +165,12 @@ struct FzSelectParams {
     uint32_t flat;            // 1: every passing score counts as min_score, so the order is by index only
     uint64_t *out_lim;        // [rows] or null: the limit the row's result sets for the tiles not in it (FzEmit)
     uint64_t *dbg;            // diagnostics (FUZZYHIP_SELECT_DEBUG=1): [rows][8] phase timestamps, or null
+    // A few rows over a large shard: the 64-position tiles of every row are dealt round-robin to n_slices blocks
+    // (blockIdx.y; a power of two), each block selects the top-k of its tiles, and the block that finishes last
+    // merges the row's n_slices * k keys (n_slices * k <= FZ_MAX_K).  n_slices <= 1: one block per row.
+    uint32_t n_slices;
+    uint64_t *slice_keys;     // [rows][n_slices][k]
+    uint32_t *slice_done;     // [rows] blocks of the row that have written their keys; zero before the launch
 };
 
 // ---- two scorers combined through a rank table (fz_query_topk_pair) ------------------------------

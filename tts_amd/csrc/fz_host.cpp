@@ -213,6 +213,10 @@ struct fz_corpus {
     uint32_t stream_oversub = 1;                          // FUZZYHIP_STREAM_OVERSUB: persistent blocks per slot
     uint32_t pipe_chunks = 1;                             // FUZZYHIP_CHUNKS: pieces of a large top-k batch
     uint32_t stream_waves = 0, stream_blocks = 192;       // tuning knobs (FUZZYHIP_STREAM_WAVES: waves per block, 0 = by kernel; _BLOCKS)
+    // sliced select (FzSelectParams::n_slices): a few rows over a large shard are selected by several blocks per row
+    uint64_t *d_slice_keys = nullptr; uint32_t *d_slice_done = nullptr;
+    uint32_t select_slice = 65536, select_slice_rows = 8;  // FUZZYHIP_SELECT_SLICE (positions per block, 0: off), rows up to which rows are sliced
+    uint32_t stream_min_queries = 8;                      // FUZZYHIP_STREAM_MIN_QUERIES: smaller batches take the general kernel for every tile
     uint32_t stream_max_group = 1024;                     // most queries one work item takes (FUZZYHIP_STREAM_MAX_GROUP); its waves share them out
     std::vector<hipEvent_t> events;
     fz_timing timing{};
@@ -317,7 +321,8 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
     for (View &v : c->views) free_view(v);
     Workspace &w = c->own_ws;
     for (void *p : {(void *)w.d_scores, (void *)w.d_qbuf, (void *)w.d_keys, (void *)w.d_cnt,
-                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1], (void *)c->d_ranks, (void *)c->d_rank_tab, (void *)w.d_counters})
+                    (void *)c->d_score_tab[0], (void *)c->d_score_tab[1], (void *)c->d_ranks, (void *)c->d_rank_tab, (void *)w.d_counters,
+                    (void *)c->d_slice_keys, (void *)c->d_slice_done})
         if (p) (void)hipFree(p);
     for (int i = 0; i < 2; ++i) {
         if (c->h_blob[i]) (void)hipHostFree(c->h_blob[i]);
@@ -650,6 +655,11 @@ static int finish_create(fz_corpus *c)
         void *scratch = nullptr; size_t scratch_bytes = 0;
         HIP_TRY(fz_scratch_acquire(c->device, &scratch, &scratch_bytes));
     }
+    if (const char *e = getenv("FUZZYHIP_SELECT_SLICE")) c->select_slice = (uint32_t)std::max(0, atoi(e)) & ~15u;
+    if (const char *e = getenv("FUZZYHIP_STREAM_MIN_QUERIES")) c->stream_min_queries = (uint32_t)std::max(0, atoi(e));
+    HIP_TRY(hipMalloc((void **)&c->d_slice_keys, (size_t)FZ_MAX_K * 8 * c->select_slice_rows));
+    HIP_TRY(hipMalloc((void **)&c->d_slice_done, 256));
+    HIP_TRY(hipMemset(c->d_slice_done, 0, 256));
     if (const char *e = getenv("FUZZYHIP_STREAM_OVERSUB")) c->stream_oversub = (uint32_t)std::min(16, std::max(1, atoi(e)));
     if (const char *e = getenv("FUZZYHIP_CHUNKS")) c->pipe_chunks = (uint32_t)std::min(64, std::max(1, atoi(e)));
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
@@ -1372,7 +1382,10 @@ static int prepare_rows(fz_corpus *c, int view_kind, int kmode, const uint32_t *
     auto t0 = std::chrono::steady_clock::now();
     QueryBatch &b = P.b;
     const bool stream_mode = kmode == FZ_MODE_TOKEN_SET || kmode == FZ_MODE_RATIO;
-    b.allow_stream = c->use_stream && stream_mode && (v.n_s0 + v.n_s1 + v.n_s2) > 0;
+    // a handful of queries: the general kernel over every tile (query as the pattern, nothing to set up per tile) beats
+    // the stream kernels, whose per-tile set-up pays off from about 8 queries on (1 query x 10^6 candidates: 0.022 ms
+    // against 0.11 ms)
+    b.allow_stream = c->use_stream && stream_mode && (v.n_s0 + v.n_s1 + v.n_s2) > 0 && rows >= c->stream_min_queries;
     // the score table covers L < 128; a stream tile holds at most 64 symbols.  token_set looks up
     // L = m + clen - 2, ratio L = m + clen.
     b.stream_max_m = kmode == FZ_MODE_TOKEN_SET ? (FZ_STREAM_TAB + 1u - 64u) : (FZ_STREAM_TAB - 1u - 64u);
@@ -1646,6 +1659,14 @@ static int run_matrix(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_off
             sp.min_score = t.min_score; sp.k = t.k; sp.base_index = c->base;
             sp.out_keys = t.d_keys + q0 * t.k; sp.out_cnt = t.d_cnt ? t.d_cnt + q0 : nullptr;
             sp.flat = t.flat;
+            // a few rows over a large shard (single-query latency: reference src/synapse_agent.py:517-518 asks one entity at
+            // a time): one block would walk the whole row, so the row is cut into runs, one block each, and the block that
+            // finishes last merges the row's keys
+            if (!w.fixed && c->select_slice != 0u && rows <= c->select_slice_rows && c->n >= 2ull * c->select_slice && t.k != 0u && 2u * t.k <= FZ_MAX_K) {
+                uint32_t S = 1u;                                  // a power of two: blocks per row
+                while (2u * S * t.k <= FZ_MAX_K && (uint64_t)2u * S * c->select_slice <= c->n) S *= 2u;
+                if (S > 1u) { sp.n_slices = S; sp.slice_keys = c->d_slice_keys; sp.slice_done = c->d_slice_done; }
+            }
             struct DevFree { void operator()(uint64_t *p) const { if (p) (void)hipFree(p); } };
             std::unique_ptr<uint64_t, DevFree> dbg_holder;       // freed on the early returns below too
             uint64_t *d_dbg = nullptr;

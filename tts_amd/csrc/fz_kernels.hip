@@ -846,7 +846,8 @@ __device__ __forceinline__ void fz_wave_queries(const FzStreamParams &p, uint32_
 }
 
 template <int W, int MODE, int STRIDE, bool EMIT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 5, 8)))      // two pattern words: 96 registers, 5 waves per SIMD
+__global__ __launch_bounds__(512)
+__attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 5, 8)))      // two pattern words: 96 registers, 5 waves per SIMD   // EMUL: /* occupancy hint: no meaning on the host */
 void fz_score_stream(FzStreamParams p, const FzRec *__restrict__ recs, uint8_t *__restrict__ scores)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -877,7 +878,7 @@ void fz_score_stream(FzStreamParams p, const FzRec *__restrict__ recs, uint8_t *
         for (int w = 0; w < W; ++w)
             for (uint32_t r = wave; r < (uint32_t)STRIDE; r += nw) *reinterpret_cast<uint32_t *>(col + (uint32_t)w * PLANE + r * 4u) = 0u;
         __syncthreads();                                 // the item is known, the column is clear
-        const uint32_t item = s_ctl[0];
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ctl[0]);   // the same for every lane: keep what follows scalar
         if (item == 0xFFFFFFFFu) break;
         uint32_t qgroup, tix;
         fz_item_decode(item, p.ntiles, p.slab_units, (p.nq + p.q_per_block - 1u) / p.q_per_block, qgroup, tix);
@@ -1113,7 +1114,8 @@ __device__ __forceinline__ void fz_stream_queries_pk(const FzStreamParams &p, co
 }
 
 template <int MODE, int STRIDE, bool EMIT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(512)
+__attribute__((amdgpu_waves_per_eu(8, 8)))                   // 64 registers: 8 waves per SIMD   // EMUL: /* occupancy hint: no meaning on the host */
 void fz_score_stream_pk(FzStreamParams p, const FzRec *__restrict__ recs, uint8_t *__restrict__ scores)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -1143,7 +1145,7 @@ void fz_score_stream_pk(FzStreamParams p, const FzRec *__restrict__ recs, uint8_
         }
         for (uint32_t r = wave; r < (uint32_t)STRIDE; r += nw) *reinterpret_cast<uint32_t *>(col + r * 4u) = 0u;
         __syncthreads();
-        const uint32_t item = s_ctl[0];
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ctl[0]);   // the same for every lane: keep what follows scalar
         if (item == 0xFFFFFFFFu) break;
         uint32_t qgroup, pair;
         fz_item_decode(item, npairs, p.slab_units, (p.nq + p.q_per_block - 1u) / p.q_per_block, qgroup, pair);
@@ -1400,8 +1402,18 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
     __shared__ uint32_t s_ties[SEL_TIECAP];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t row = blockIdx.x, n = p.n, k = p.k;
+    const uint32_t row = blockIdx.x, k = p.k;
+    // A sliced row (a few rows over a large shard) is dealt out tile by tile: block `slice` of the row's S blocks takes
+    // the 64-position tiles t with t % S == slice, so every block sees every length class and original indices from
+    // the whole range (runs of consecutive positions would not: inside a length class the physical order is the
+    // original order, and the walk below would have to pass most of the list to reach a late run).  S is a power of two.
+    const uint32_t S = p.n_slices > 1u ? p.n_slices : 1u, slice = p.n_slices > 1u ? blockIdx.y : 0u;
+    const uint32_t tiles_all = (p.n + 63u) >> 6;
+    // local position l (what the passes below count in) -> physical position: tile (l >> 6) * S + slice, byte l & 63
+    const uint32_t n = S > 1u ? (tiles_all > slice ? ((tiles_all - slice + S - 1u) / S) << 6 : 0u) : p.n;
     const uint8_t *sc = p.scores + (uint64_t)row * p.row_stride;
+    const uint32_t *orig_of_phys = p.orig_of_phys;
+#define FZ_SEL_PHYS(l) (S > 1u ? ((((l) >> 6) * S + slice) << 6) + ((l) & 63u) : (l))
     const uint32_t min_score = p.min_score < 0 ? 0u : (uint32_t)p.min_score;
 
     if (tid < 128u) s_hist[tid] = 0u;
@@ -1421,22 +1433,29 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
     // at sstar + 1 as well), so an unmarked vector holds nothing pass B would take.  After the first
     // update of the bound (two iterations) almost no vector is marked.  Rows of more than 64 vectors per
     // thread (> 2^20 candidates) are read in full.
-    const uint32_t per_iter = THREADS * 16u * SEL_VEC;
-    const uint32_t niter = (n + per_iter - 1u) / per_iter;
-    const bool track = niter * SEL_VEC <= 64u;
+    // Every thread takes nv 16-byte vectors, vector i of thread t at local position (i * THREADS + t) * 16.  They go in
+    // groups: the FIRST group is one vector per thread, so that the bound rises after THREADS * 16 positions already
+    // (a k-th best of a prefix is a valid lower bound of the row's; until the first update everything >= min_score takes
+    // the slow path below), then SEL_VEC vectors at a time.
+    const uint32_t nv = (n + THREADS * 16u - 1u) / (THREADS * 16u);
+    const bool track = nv <= 64u;
     uint64_t seen = 0ull;
-    for (uint32_t it = 0; it < niter; ++it) {
+    uint32_t upd = 0u;
+    for (uint32_t v0 = 0u; v0 < nv; ) {
+        const uint32_t gcnt = v0 == 0u ? 1u : SEL_VEC;
         const uint32_t tlow = s_misc[8];                     // count scores >= this (<= 101)
         const uint32_t add = 0x01010101u * (128u - (tlow ? tlow : 1u));
         uint4 v[SEL_VEC];
 #pragma unroll
         for (uint32_t j = 0; j < SEL_VEC; ++j) {
-            const uint32_t base = ((it * SEL_VEC + j) * THREADS + tid) * 16u;
-            v[j] = base < n ? *reinterpret_cast<const uint4 *>(sc + base) : uint4{0u, 0u, 0u, 0u};
+            const uint32_t base = ((v0 + j) * THREADS + tid) * 16u;
+            v[j] = (j < gcnt && base < n) ? *reinterpret_cast<const uint4 *>(sc + FZ_SEL_PHYS(base)) : uint4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (uint32_t j = 0; j < SEL_VEC; ++j) {
-            const uint32_t base = ((it * SEL_VEC + j) * THREADS + tid) * 16u;
+            if (j >= gcnt) break;                                            // (uniform)
+            const uint32_t base = ((v0 + j) * THREADS + tid) * 16u;
+            const uint32_t pbase = FZ_SEL_PHYS(base);
             const uint32_t wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
             uint32_t any = 0u;
 #pragma unroll
@@ -1450,12 +1469,14 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
                     m &= m - 1u;
                     uint32_t s = (wv[a] >> sh) & 0xFFu;                  // a byte > 100 is not a score: skipped
                     if (p.flat && s >= min_score) s = s <= 100u ? min_score : s;   // index order only
-                    fz_hist_add(s_hist, s, on && s >= tlow && s <= 100u && base + (uint32_t)(4 * a) + (sh >> 3) < n);
+                    fz_hist_add(s_hist, s, on && s >= tlow && s <= 100u && base < n && pbase + (uint32_t)(4 * a) + (sh >> 3) < p.n);
                 }
             }
-            if (track && any != 0u) seen |= 1ull << (it * SEL_VEC + j);
+            if (track && any != 0u) seen |= 1ull << (v0 + j);
         }
-        if (it == 0u || (it & 1u) == 1u) fz_sel_update(s_hist, s_cum, s_misc, k);   // early first update: the bound rises after 64 Ki candidates
+        v0 += gcnt;
+        if (upd < 2u || (upd & 1u) == 0u) fz_sel_update(s_hist, s_cum, s_misc, k);   // after the first two groups, then every other one
+        ++upd;
     }
     fz_sel_update(s_hist, s_cum, s_misc, k);
 
@@ -1472,17 +1493,17 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
         // ties are collected here only when they are few enough to sort; otherwise look at better scores only
         const uint32_t bfil = (few_ties && need > 0u) ? sstar : sstar + 1u;
         const uint32_t add = 0x01010101u * (128u - (bfil ? bfil : 1u));
-        for (uint32_t it = 0; it < niter; ++it) {
+        for (uint32_t v0 = 0u; v0 < nv; v0 += SEL_VEC) {
             uint4 v[SEL_VEC];
 #pragma unroll
             for (uint32_t j = 0; j < SEL_VEC; ++j) {
-                const uint32_t base = ((it * SEL_VEC + j) * THREADS + tid) * 16u;
-                const bool want = !track || ((seen >> (it * SEL_VEC + j)) & 1ull) != 0ull;
-                v[j] = (base < n && want) ? *reinterpret_cast<const uint4 *>(sc + base) : uint4{0u, 0u, 0u, 0u};
+                const uint32_t base = ((v0 + j) * THREADS + tid) * 16u;
+                const bool want = !track || ((seen >> (v0 + j)) & 1ull) != 0ull;
+                v[j] = (base < n && want) ? *reinterpret_cast<const uint4 *>(sc + FZ_SEL_PHYS(base)) : uint4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
             for (uint32_t j = 0; j < SEL_VEC; ++j) {
-                const uint32_t base = ((it * SEL_VEC + j) * THREADS + tid) * 16u;
+                const uint32_t base = FZ_SEL_PHYS(((v0 + j) * THREADS + tid) * 16u);     // physical from here on
                 const uint32_t wv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -1493,13 +1514,13 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
                         uint32_t s = (wv[a] >> sh) & 0xFFu;
                         if (p.flat && s >= min_score) s = s <= 100u ? min_score : s;
                         const uint32_t ph = base + (uint32_t)(4 * a) + (sh >> 3);
-                        if (ph < n && s >= sstar && s <= 100u) {
+                        if (ph < p.n && s >= sstar && s <= 100u) {
                             if (s > sstar) {
                                 uint32_t pos = atomicAdd(&s_misc[2], 1u);
-                                s_keys[pos] = fz_local_key(s, p.orig_of_phys[ph]);
+                                s_keys[pos] = fz_local_key(s, orig_of_phys[ph]);
                             } else if (few_ties && need > 0u) {
                                 uint32_t pos = atomicAdd(&s_misc[3], 1u);
-                                s_ties[pos] = p.orig_of_phys[ph];
+                                s_ties[pos] = orig_of_phys[ph];
                             }
                         }
                     }
@@ -1557,7 +1578,7 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
                 bool pred = false;
                 if (o < p.n_orig) {
                     const uint32_t ph = p.phys_of_orig[o];
-                    if (ph < n) {                                                // a row may hold only the front of the physical order
+                    if (ph < p.n && ((ph >> 6) & (S - 1u)) == slice) {           // a row may hold only the front of the physical order; a block only its tiles
                         const uint32_t s = sc[ph];
                         pred = p.flat ? (s >= sstar && s <= 100u) : (s == sstar);    // flat: sstar == min_score
                     }
@@ -1586,6 +1607,49 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
     FZ_DBG(4);
     if (p.dbg && tid == 0u) { p.dbg[(uint64_t)row * 8u + 5u] = c_eq; p.dbg[(uint64_t)row * 8u + 6u] = need; p.dbg[(uint64_t)row * 8u + 7u] = sstar; }
 
+    if (p.n_slices > 1u) {
+        // ---- sliced row: leave this run's keys, and merge the row if this block is the last one to finish -------
+        const uint32_t S = p.n_slices;
+        uint64_t *mine = p.slice_keys + ((uint64_t)row * S + blockIdx.y) * k;
+        for (uint32_t i = tid; i < k; i += blockDim.x) {
+            uint64_t out = 0ull;
+            if (i < total) {
+                const uint64_t key = s_keys[i];
+                const uint64_t gidx = p.base_index + (uint64_t)(0xFFFFFFFFu - (uint32_t)key);
+                out = ((key >> 32) << FZ_IDX_BITS) | (FZ_IDX_MASK - gidx);
+            }
+            __hip_atomic_store(&mine[i], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0u) s_misc[1] = atomicAdd(&p.slice_done[row], 1u);
+        __syncthreads();
+        if (s_misc[1] != S - 1u) return;                      // (uniform for the block)
+        __threadfence();
+        const uint32_t all = S * k;                           // <= FZ_MAX_K (host)
+        uint32_t P2 = 2u;
+        while (P2 < all) P2 <<= 1;
+        __syncthreads();
+        for (uint32_t i = tid; i < P2; i += blockDim.x)       // the other blocks' keys: loads that bypass this CU's L1
+            s_keys[i] = i < all ? __hip_atomic_load(&p.slice_keys[(uint64_t)row * all + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        __syncthreads();
+        fz_bitonic<uint64_t, true>(s_keys, P2);
+        uint32_t cnt = 0u;
+        for (uint32_t i = tid; i < k; i += blockDim.x) {
+            const uint64_t v = s_keys[i];
+            p.out_keys[(uint64_t)row * k + i] = v;
+            cnt += v != 0ull ? 1u : 0u;
+        }
+        if (tid == 0u) s_misc[2] = 0u;
+        __syncthreads();
+        if (cnt) atomicAdd(&s_misc[2], cnt);
+        __syncthreads();
+        if (tid == 0u) {
+            if (p.out_cnt != nullptr) p.out_cnt[row] = s_misc[2];
+            p.slice_done[row] = 0u;                           // ready for the next launch
+        }
+        return;
+    }
     for (uint32_t i = tid; i < k; i += blockDim.x) {
         uint64_t out = 0ull;
         if (i < total) {
@@ -2053,6 +2117,13 @@ hipError_t fz_launch_score(int W, int mode, const FzScoreParams &p, uint32_t nq,
 hipError_t fz_launch_select(const FzSelectParams &p, uint32_t rows, hipStream_t st)
 {
     if (rows == 0u || p.k == 0u) return hipSuccess;
+    if (p.n_slices > 1u) {
+        if ((uint64_t)p.n_slices * p.k > FZ_MAX_K || (p.n_slices & (p.n_slices - 1u)) || !p.slice_keys || !p.slice_done || p.out_lim || p.walk)
+            return hipErrorInvalidValue;
+        if (p.n / p.n_slices <= 262144u) hipLaunchKernelGGL(fz_select_topk<256u>, dim3(rows, p.n_slices), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(fz_select_topk<1024u>, dim3(rows, p.n_slices), dim3(1024), 0, st, p);
+        return hipGetLastError();
+    }
     if (p.n <= 262144u) hipLaunchKernelGGL(fz_select_topk<256u>, dim3(rows), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(fz_select_topk<1024u>, dim3(rows), dim3(1024), 0, st, p);
     return hipGetLastError();
