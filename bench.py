@@ -61,32 +61,57 @@ def load_json(name):
         return None
 
 
-def pmc_counts(nq, n, max_chars, k):
+def pmc_counts(wl, nq, n, max_chars, k):
     """Per-step instruction counts and HBM bytes of the score kernels from the committed rocprofv3 --pmc
-    passes (profiles/pmc_current.json, written by tools/publish_profile.py).  Counts are a property of
-    (sources, workload): None unless both match this run."""
-    t = load_json("pmc_current.json")
-    if not t:
-        return None, "no profiles/pmc_current.json"
-    w = t.get("workload", {})
-    if (w.get("queries"), w.get("candidates_per_gpu"), w.get("max_chars"), w.get("k")) != (nq, n, max_chars, k):
-        return None, "committed PMC pass is for another workload"
-    if t.get("source_hash") != source_hash():
-        return None, f"committed PMC pass was taken on other sources ({t.get('source_hash')} != {source_hash()})"
-    return t, None
+    passes (profiles/pmc_current*.json, one per profiled workload, written by tools/publish_profile.py).
+    Counts are a property of (sources, workload): None unless both match this run."""
+    why = "no profiles/pmc_current*.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_current*.json"))):
+        t = load_json(os.path.basename(path))
+        if not t:
+            continue
+        w = t.get("workload", {})
+        if (w.get("workload_id", "C2"), w.get("queries"), w.get("candidates_per_gpu"), w.get("max_chars"), w.get("k")) != (wl, nq, n, max_chars, k):
+            why = "the committed PMC passes are for other workloads"
+            continue
+        if t.get("source_hash") != source_hash():
+            return None, f"the committed PMC pass of this workload was taken on other sources ({t.get('source_hash')} != {source_hash()})"
+        return t, None
+    return None, why
+
+
+SIMDS = 1024             # 256 CUs x 4 SIMD-32 (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
 def valu_peak():
-    """Chip-wide wave64 VALU instructions/s measured by tools/valu_rate.hip at the kernels' occupancy
-    (4 waves per SIMD), and the clock it was measured at."""
+    """Two ceilings for wave64 VALU instructions per second.  The chip's: a SIMD-32 issues a wave64 VALU instruction
+    in 2 cycles (the guide's figure), so SIMDS x clock / 2, at the shader clock tools/valu_rate.hip measured inside
+    its kernels.  And what that microbenchmark sustains with plain v_bitop3_b32 at the stream kernels' occupancy
+    (8 waves per SIMD), which is higher than 2 cycles per instruction suggests (1.46)."""
     t = load_json("valu_rate_current.json")
     if not t:
         return None
     best = None
     for r in t.get("results", []):
-        if r.get("waves_per_simd") == 4 and r["kind"].startswith("v_bitop3_b32"):
+        if r.get("waves_per_simd") == 8 and r["kind"].startswith("v_bitop3_b32"):
             best = r
-    return best
+    if not best:
+        return None
+    return {"clock_ghz": best["clock_ghz"], "chip_2cyc": SIMDS * best["clock_ghz"] / 2.0,
+            "measured_at_occupancy": best["chip_ginstr_per_s"], "measured_cycles_per_instr": best["cycles_per_instr_per_simd"]}
+
+
+def step_instructions(queries, info, max_chars):
+    """Wave instructions per bench step that ARE the algorithm: one Hyyro step = 3 lane operations (and / add / or-xor)
+    per pattern word per query symbol, token separators included, for every unit a wave takes a query through: a
+    packed pair of tiles (one word for two candidates), a one-word tile, a two-word tile (2 x 3).  Padding steps,
+    addressing, token-id compares, masks and look-ups are not in it."""
+    steps = 0
+    for q in queries:
+        toks = sorted(set(q.split()))
+        steps += sum(len(t) + 1 for t in toks)
+    units = info.get("n_packed_pairs", 0) + info.get("n_stream1_tiles", 0) + 2 * info.get("n_stream2_tiles", 0)
+    return 3.0 * steps * units
 
 
 def cpu_baseline(cps, offs, queries, min_score, k, budget_s=10.0):
@@ -348,35 +373,37 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         score_s = score_ms * 1e-3 / steps                      # this rank's score phase per step (hipEvents)
-        # ---- the ceiling that binds: integer issue (VALU; SALU beside it), not HBM ------------------------
-        pmc, pmc_why = pmc_counts(nq, n_local, args.max_chars, k) if wl == "C2" else (None, "PMC passes are taken on C2")
+        # ---- the ceiling that binds: integer issue (VALU), not HBM -------------------------------------------------
+        pmc, pmc_why = pmc_counts(wl, nq, n_local, args.max_chars, k)
         peak = valu_peak()
         roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave64 VALU instructions/s",
                 "frac": None, "traffic": None,
-                "kernel": "fz_score_stream_pk + fz_score_stream<1> + fz_score_stream<2> (the score launches of a step: sample tiles, then the rest)",
+                "kernel": "the score kernels of a step (fz_score_stream_pk + fz_score_stream<1> + fz_score_stream<2>; fz_score_general "
+                          "for long strings): sample tiles first, then the rest",
                 "kernel_ms_per_step": score_ms / steps, "launches_per_step": launches / steps,
                 "how": "achieved = VALU instructions of the score kernels per step (rocprofv3 --pmc SQ_INSTS_VALU, "
-                       "profiles/pmc_current.json, quoted only when its source hash and workload match this run) / the score "
-                       "phase's duration measured live (hipEvents on the library's stream); peak = tools/valu_rate.hip on "
-                       "this chip at 4 waves per SIMD (profiles/valu_rate_current.json)"}
+                       "profiles/pmc_current*.json, quoted only when source hash and workload match this run) / the score "
+                       "phase's duration measured live (hipEvents on the library's stream); peak = 1024 SIMDs x shader clock / "
+                       "2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md; clock measured by tools/valu_rate.hip); "
+                       "frac_at_kernel_occupancy = achieved / what that microbenchmark sustains with plain VALU at 8 waves per SIMD"}
         if peak:
-            roof["peak"] = peak["chip_ginstr_per_s"]
-            roof["peak_cycles_per_instr_per_simd"] = peak["cycles_per_instr_per_simd"]
+            roof["peak"] = peak["chip_2cyc"]
             roof["peak_clock_ghz"] = peak["clock_ghz"]
+            roof["peak_measured_at_kernel_occupancy"] = peak["measured_at_occupancy"]
         if pmc and score_s > 0:
             roof["achieved"] = pmc["score_insts_valu_per_step"] / score_s / 1e9
             roof["traffic"] = pmc["score_kernels_bytes_per_step"]
             roof["traffic_unit"] = "HBM bytes per step of the score kernels: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, separate passes"
-            roof["salu_insts_per_cu_cycle"] = pmc.get("salu_insts_per_cu_cycle_dominant")
             roof["valu_insts_per_step"] = pmc["score_insts_valu_per_step"]
             roof["salu_insts_per_step"] = pmc.get("score_insts_salu_per_step")
+            roof["all_insts_per_step"] = pmc.get("score_insts_all_per_step")
+            roof["valu_issue_frac_2cyc_dominant_kernel_profiled"] = pmc.get("valu_issue_frac_2cyc_dominant")
             if roof["peak"]:
                 roof["frac"] = roof["achieved"] / roof["peak"]
-                # every wave instruction (vector, scalar, LDS, memory) takes an issue slot of its SIMD: the same
-                # ratio over ALL instructions says how full the issue slots are, bookkeeping included
-                if pmc.get("score_insts_all_per_step"):
-                    roof["all_instructions_G_per_s"] = pmc["score_insts_all_per_step"] / score_s / 1e9
-                    roof["issue_slots_frac"] = roof["all_instructions_G_per_s"] / roof["peak"]
+                roof["frac_at_kernel_occupancy"] = roof["achieved"] / peak["measured_at_occupancy"]
+            if wl != "C4" and pmc.get("score_insts_all_per_step"):
+                # how much of what issues is the algorithm proper (Hyyro steps on real symbols), by count
+                roof["algorithm_instr_frac"] = step_instructions(queries, info, args.max_chars) / pmc["score_insts_all_per_step"]
             roof["wave_cycles_waiting_frac"] = pmc.get("score_wave_cycles_waiting_frac")
         else:
             roof["why_null"] = pmc_why
@@ -391,7 +418,7 @@ def main():
                        "query batching; a wave scores one tile against Q_b queries out of LDS and the shard is cache "
                        "resident, so algorithmic_over_peak may exceed 1 and is not a fraction of HBM; frac is measured "
                        "FETCH+WRITE bytes / score time / peak",
-               "Q_b": pmc.get("queries_per_tile_pass") if pmc else None}
+               "Q_b": "a work item takes one tile (or pair of tiles) through a group of up to 1024 queries out of LDS: the whole batch at C2"}
         if pmc and score_s > 0:
             hbm["achieved"] = pmc["score_kernels_bytes_per_step"] / score_s / 1e9
             hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBPS
@@ -405,7 +432,7 @@ def main():
                            "C2": f"C2: {nq} queries x {n_local} candidates/GPU (<= {args.max_chars} chars, Zipf(1.2) tokens over 50k vocabulary), top-{k}, threshold {args.threshold}",
                            "C3": f"C3: {nq} queries x {n_all} candidates in ONE corpus sharded over {world} GPU(s) by contiguous index ranges ({n_local}/GPU, <= {args.max_chars} chars), all-gather top-{k}, threshold {args.threshold}",
                            "C4": f"C4: {nq} queries x {n_local} candidates/GPU (8-60 tokens, <= {args.max_chars} chars, multi-word patterns), top-{k}, threshold {args.threshold}"}[wl],
-                       "queries": nq, "candidates_per_gpu": n_local, "candidates_total": n_all, "k": k, "min_score": min_score,
+                       "workload_id": wl, "max_chars": args.max_chars, "queries": nq, "candidates_per_gpu": n_local, "candidates_total": n_all, "k": k, "min_score": min_score,
                        "parallelism": (f"shard{world}" if world > 1 else "single") + ("-rehearsal-gloo" if rehearsal else "")},
             "roofline": roof,
             "roofline_hbm": hbm,

@@ -44,9 +44,10 @@ typedef enum {
     FZ_TOKEN_SET = 0,   /* fuzz.token_set_ratio  -- reference src/fuzzy_search.py:26, app.py:1026 */
     FZ_RATIO = 1,       /* fuzz.ratio            -- reference app.py:1010 */
     FZ_TOKEN_SORT = 2,  /* fuzz.token_sort_ratio -- BASELINE.json config 5 */
-    FZ_PARTIAL = 3,     /* fuzz.partial_ratio    -- reference app.py:1023 */
-    FZ_LEVENSHTEIN = 4  /* uniform-cost Levenshtein similarity -- reference app.py:296-317,429-432 */
+    FZ_PARTIAL = 3      /* fuzz.partial_ratio    -- reference app.py:1023 */
 } fz_scorer;
+/* The uniform-cost Levenshtein of reference app.py:296-317 is not a 0..100 scorer (app.py:429-432 turns the distance
+ * into an unrounded fp64 similarity on the host): its distances come from fz_distance_all / fz_distance_batch (kind 1). */
 
 /* OR into `scorer` of fz_query_topk / fz_query_topk_keys: every candidate that passes min_score
  * counts as a tie, so the results are the FIRST k passing candidates in list order (their score is
@@ -79,6 +80,10 @@ typedef struct {
     uint64_t total_symbols;  /* sum of canonical lengths without the trailing separator */
     uint64_t total_tokens;   /* sum of token counts */
     int32_t device;
+    /* how the tiles of the token_set view are dealt to the kernels: pairs of short tiles sharing one pattern word
+     * (fz_score_stream_pk), tiles with one / two pattern words of their own (fz_score_stream<1> / <2>), and tiles
+     * only the general kernel takes (long or many-token candidates, wide alphabets) */
+    uint32_t n_packed_pairs, n_stream1_tiles, n_stream2_tiles, n_general_tiles;
 } fz_info;
 
 typedef struct {
@@ -170,7 +175,9 @@ int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, u
 
 /*
  * fz_query_topk_noalloc -- fz_query_topk for callers that cannot allocate device memory while they run:
- * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
+ * tight serving loops, harnesses that forbid hipMalloc, processes whose device memory is spoken for.  (Not for a
+ * stream under graph capture: like fz_query_topk the call synchronises its stream, copies results to the host and
+ * decodes them there; it makes no device or pinned allocation, that is all it promises.)  It has NO
  * counterpart in the reference (whose loop allocates Python objects per candidate, src/fuzzy_search.py:22-32).
  * Same arguments, same results bit for bit; it calls no hipMalloc / hipFree / hipHostMalloc / hipEventCreate
  * and no other allocating HIP routine.  Its device scratch -- work-queue counters, query tables, the score

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 tag, name = sys.argv[1], sys.argv[2]
 json_only = name == "--json-only"
+STEPS = int(os.environ.get("PROF_STEPS", "4"))      # bench steps the profiled command ran (warm-up + timed)
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
@@ -39,7 +40,7 @@ def derive():
     kernels = {k for k, _ in fetch}
     score = sorted(k for k in kernels if "fz_score" in k)
     other = sorted(k for k in kernels if "fz_" in k and "fz_score" not in k)
-    steps = 4                                                   # 1 warm-up + 3 timed steps were profiled
+    steps = STEPS                                               # warm-up + timed steps of the profiled command
     kib = 1024.0
     sf = sum(fetch[(k, "FETCH_SIZE")][1] for k in score) * kib * 2 / steps
     sw = sum(write[(k, "WRITE_SIZE")][1] for k in score) * kib / steps
@@ -67,12 +68,14 @@ def derive():
     cfg = line["config"]
     main_k = max(score, key=lambda k: grbm[(k, "GRBM_GUI_ACTIVE")][1])
     return {
-        "source": f"rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, GRBM_* each in its own run) of "
-                  f"`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-reps 0` on MI355X, tag {tag}",
-        "units": "per step = per bench step (sums over the 4 profiled steps / 4); FETCH_SIZE is KiB and is doubled "
+        "source": f"rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, GRBM_* each in its own run) of the profiled "
+                  f"command on MI355X, tag {tag}",
+        "units": f"per step = per bench step (sums over the {STEPS} profiled steps / {STEPS}); FETCH_SIZE is KiB and is doubled "
                  "(gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM); WRITE_SIZE is KiB",
         "source_hash": bench.source_hash(),
-        "workload": {"queries": cfg["queries"], "candidates_per_gpu": cfg["candidates_per_gpu"], "max_chars": 64, "k": cfg["k"]},
+        "workload": {"workload_id": cfg.get("workload_id", "C2"), "queries": cfg["queries"], "candidates_per_gpu": cfg["candidates_per_gpu"],
+                     "max_chars": cfg.get("max_chars", 64), "k": cfg["k"]},
+        "profiled_command": os.environ.get("PROF_CMD", "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-reps 0"),
         "score_kernels_bytes_per_step": int(sf + sw),
         "score_fetch_bytes_per_step": int(sf),
         "score_write_bytes_per_step": int(sw),
@@ -86,7 +89,6 @@ def derive():
         "dominant_score_kernel": main_k,
         "salu_insts_per_cu_cycle_dominant": per[main_k]["salu_insts_per_cu_cycle"],
         "valu_issue_frac_2cyc_dominant": per[main_k]["valu_issue_frac_2cyc"],
-        "queries_per_tile_pass": ">= 32 (a work item takes one tile, or pair of tiles, through a group of 32 to 256 queries out of LDS; 200 at C2)",
         "per_kernel": per,
     }
 
@@ -107,7 +109,9 @@ with open(os.path.join(P, f"{name}_kernel_stats.csv"), "w", newline="") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100.0 * r[2] / total, 2), r[4], r[5]])
-for dst in (f"{name}_pmc.json", "pmc_current.json"):
+wl_id = out["workload"]["workload_id"]
+suffix = os.environ.get("PROF_SUFFIX", "" if wl_id == "C2" else "_" + wl_id)
+for dst in (f"{name}_pmc.json", f"pmc_current{suffix}.json"):
     with open(os.path.join(P, dst), "w") as f:
         json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))

@@ -11,9 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FUZZYHIP_LIB: another build of the same library (kernel experiments, A/B runs on one box)
 LIB_PATH = os.environ.get("FUZZYHIP_LIB") or os.path.join(_HERE, "libfuzzyhip.so")
 
-TOKEN_SET, RATIO, TOKEN_SORT, PARTIAL, LEVENSHTEIN = 0, 1, 2, 3, 4
-SCORERS = {"token_set": TOKEN_SET, "ratio": RATIO, "token_sort": TOKEN_SORT, "partial": PARTIAL,
-           "levenshtein": LEVENSHTEIN}
+TOKEN_SET, RATIO, TOKEN_SORT, PARTIAL = 0, 1, 2, 3
+SCORERS = {"token_set": TOKEN_SET, "ratio": RATIO, "token_sort": TOKEN_SORT, "partial": PARTIAL}
 ORDER_BY_INDEX = 0x100
 MAX_K = 1024
 IDX_BITS = 40
@@ -31,7 +30,9 @@ class FzInfo(ctypes.Structure):
                 ("alphabet_size", ctypes.c_uint32), ("n_tiles", ctypes.c_uint32),
                 ("max_len", ctypes.c_uint32), ("max_tokens", ctypes.c_uint32),
                 ("device_bytes", ctypes.c_uint64), ("total_symbols", ctypes.c_uint64),
-                ("total_tokens", ctypes.c_uint64), ("device", ctypes.c_int32)]
+                ("total_tokens", ctypes.c_uint64), ("device", ctypes.c_int32),
+                ("n_packed_pairs", ctypes.c_uint32), ("n_stream1_tiles", ctypes.c_uint32),
+                ("n_stream2_tiles", ctypes.c_uint32), ("n_general_tiles", ctypes.c_uint32)]
 
 
 class FzTiming(ctypes.Structure):

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <map>
 #include <memory>
 #include <new>
@@ -903,6 +904,7 @@ extern "C" int fz_corpus_info(const fz_corpus *c, fz_info *o)
     o->max_tokens = v.max_tok; o->device_bytes = 0;
     for (const View &w : c->views) o->device_bytes += w.device_bytes;
     o->total_symbols = v.total_symbols; o->total_tokens = v.total_tokens; o->device = c->device;
+    o->n_packed_pairs = v.n_s0 / 2u; o->n_stream1_tiles = v.n_s1; o->n_stream2_tiles = v.n_s2; o->n_general_tiles = v.n_slow;
     return FZ_OK;
 }
 
@@ -1145,15 +1147,22 @@ public:
         if (!owner.owns_lock()) return false;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            while (threads_.size() + 1u < n && threads_.size() < kMaxWorkers) threads_.emplace_back([this] { worker(); });
-            if (threads_.size() + 1u < n) n = (uint32_t)threads_.size() + 1u;      // (callers ask for at most kMaxWorkers + 1)
+            try {
+                while (threads_.size() + 1u < n && threads_.size() < kMaxWorkers) threads_.emplace_back([this] { worker(); });
+            } catch (...) {}                                   // no thread to be had: what exists decides below
+            if (threads_.size() + 1u < n) return false;        // every part needs its thread: the caller builds serially instead
             job_ = &f; next_ = 1u; end_ = n; pending_ = n - 1u; ++gen_;
         }
         cv_.notify_all();
-        f(0);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [this] { return pending_ == 0u; });
-        job_ = nullptr;
+        // the workers write into the caller's frame: whatever f(0) does, nobody leaves before they are done
+        std::exception_ptr err;
+        try { f(0); } catch (...) { err = std::current_exception(); }
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            done_cv_.wait(lk, [this] { return pending_ == 0u; });
+            job_ = nullptr;
+        }
+        if (err) std::rethrow_exception(err);
         return true;
     }
     static constexpr uint32_t kMaxWorkers = 7;
@@ -1172,7 +1181,7 @@ private:
                 if (next_ >= end_) seen = gen_;
                 job = job_;
             }
-            (*job)(idx);
+            try { (*job)(idx); } catch (...) { failed_.store(true); }       // reported by run()'s caller through its own checks
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 if (--pending_ == 0u) done_cv_.notify_all();
@@ -1186,6 +1195,8 @@ private:
     uint32_t next_ = 0, end_ = 0, pending_ = 0;
     uint64_t gen_ = 0;
     std::atomic<bool> dead_{false};
+public:
+    std::atomic<bool> failed_{false};       // a worker's part threw (out of memory): set until the caller clears it
 };
 
 // The tables of rows [q0, q0 + rows) into `b`, built by `parts` threads over contiguous runs of queries.
@@ -1240,7 +1251,9 @@ static int prepare_tables_parallel(const fz_corpus *c, int view_kind, const uint
             if (pt.rc != FZ_OK) { pt.err = g_err; return; }             // g_err is this thread's own
         }
     };
-    if (!PrepPool::get().run(parts, work)) return FZ_OK;                 // pool busy: the caller builds serially
+    PrepPool::get().failed_.store(false);
+    if (!PrepPool::get().run(parts, work)) return FZ_OK;                 // pool busy or short of threads: the caller builds serially
+    if (PrepPool::get().failed_.exchange(false)) return fail(FZ_ERR_LIMIT, "out of host memory while building query tables");
     for (const Part &pt : part)
         if (pt.rc != FZ_OK) return fail(pt.rc, "%s", pt.err.c_str());
     for (Part &pt : part) {
@@ -1349,8 +1362,6 @@ static int scorer_plan(int scorer, int *view, int *mode, FzTies *ties)
     case FZ_RATIO: *view = VIEW_RAW; *mode = FZ_MODE_RATIO; *ties = g_ties_norm_sim; return FZ_OK;
     case FZ_TOKEN_SORT: *view = VIEW_SORT; *mode = FZ_MODE_RATIO; *ties = g_ties_norm_sim; return FZ_OK;
     case FZ_PARTIAL: *view = VIEW_RAW; *mode = FZ_MODE_PARTIAL; *ties = g_ties_norm_sim; return FZ_OK;
-    case FZ_LEVENSHTEIN:
-        return fail(FZ_ERR_INVALID, "FZ_LEVENSHTEIN yields distances, not 0..100 scores: use fz_distance_all / fz_distance_batch");
     default:
         return fail(FZ_ERR_INVALID, "scorer %d is not implemented by this build", scorer);
     }
