@@ -341,7 +341,7 @@ def main():
     for _ in range(args.warmup):
         step()
     score_ms = select_ms = prep_ms = 0.0
-    launches = fused_steps = fallback_chunks = 0
+    launches = fused_steps = fallback_chunks = fallback_rows = 0
     exch["gather_ms"] = exch["merge_ms"] = 0.0
     fence()
     t0 = time.perf_counter()
@@ -351,7 +351,7 @@ def main():
         t = corpus.timing()
         score_ms += t["score_ms"]; select_ms += t["select_ms"]; prep_ms += t["host_prep_ms"]
         launches += t["score_launches"]
-        fused_steps += t["fused"]; fallback_chunks += t["fused_fallback_chunks"]
+        fused_steps += t["fused"]; fallback_chunks += t["fused_fallback_chunks"]; fallback_rows += t["fused_fallback_rows"]
     fence()
     elapsed = time.perf_counter() - t0
     alg_local = float(synth.algorithmic_bytes_per_query(info))
@@ -440,7 +440,8 @@ def main():
             "kernel_pairs_per_s": float(nq) * n_local / score_s if score_s > 0 else None,
             # fused: sample tiles -> per-row limit -> appended lists -> merge (no score matrix); matrix: u8 score matrix + select
             "topk_path": "fused" if fused_steps == args.steps else ("matrix" if fused_steps == 0 else "mixed"),
-            "fused_chunks_redone_through_matrix": fallback_chunks,
+            # rows whose appended list overflowed (hits clustered where no sample tile fell) are redone through the matrix
+            "fused_rows_redone_through_matrix": fallback_rows, "fused_chunks_with_such_rows": fallback_chunks,
             "setup_seconds": setup_s,
             "source_hash": source_hash(),
             "runtime": _lib.runtime_paths(),      # the HIP runtime the library is bound to, the librccl it opened

@@ -97,7 +97,7 @@ typedef struct {
     uint32_t fused;     /* 1: the last top-k call ran fused (sample + append lists, no score matrix over the shard) */
     uint32_t fused_fallback_chunks; /* chunks of that call redone through the score matrix (list overflow) */
     float exchange_ms;  /* fz_query_topk_sharded: hipEvent time of the all-gather + device merge (0 otherwise) */
-    uint32_t reserved;
+    uint32_t fused_fallback_rows;   /* rows of that call whose appended list overflowed (redone through the score matrix) */
 } fz_timing;
 
 /* library version (FZ_VERSION of the build) */

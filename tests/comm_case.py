@@ -38,7 +38,7 @@ def same(a, b):
     return all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-def run_threads(n_ranks, names, queries, cases, exp, want_fused=False):
+def run_threads(n_ranks, names, queries, cases, exp, want_fused=False, want_overflow=()):
     box, ready = {}, threading.Event()
 
     def share(my_id):
@@ -61,6 +61,8 @@ def run_threads(n_ranks, names, queries, cases, exp, want_fused=False):
                     results[(rank, case)] = shard.topk_sharded(comm.handle, queries, ms, k, sc)
                     if want_fused:
                         assert shard.timing()["fused"] == 1, (rank, case, shard.timing())
+                    if case in want_overflow:
+                        assert shard.timing()["fused_fallback_rows"] >= 1, (rank, case, shard.timing())
                 comm.close()
         except Exception as e:          # noqa: BLE001 -- reported by the main thread
             errors.append((rank, repr(e)))
@@ -88,6 +90,28 @@ def main():
         del os.environ["FUZZYHIP_NO_FUSED"]
         for n_ranks in (2, 3):
             run_threads(n_ranks, names, queries, cases, exp, want_fused=True)
+        print("comm case ok:", mode)
+        return
+    if mode == "threads_overflow":
+        # the corpus of tests/test_gpu_fused.py::test_fused_list_overflow_falls_back, once per shard: in every shard
+        # 3 000 holders of the token 'zz' sit outside the sample tiles, so every rank's 'zz' row overflows its list
+        assert "fake_rccl" in os.environ.get("FUZZYHIP_RCCL_LIB", "") and os.environ.get("FUZZYHIP_FUSED_MIN_MB") == "0"
+        rng = np.random.default_rng(521)
+        per = 64 * 320
+        names = []
+        for shard in range(2):
+            fill = ["".join(chr(97 + int(x)) for x in rng.integers(0, 20, 6)) for _ in range(per)]
+            part = ["yy " + f for f in fill]
+            slots = [i for i in range(per) if (i // 64) % 16 != 8 and (i // 64) != per // 64 - 1]
+            for i in rng.choice(len(slots), 3000, replace=False):
+                part[slots[int(i)]] = "zz " + fill[slots[int(i)]]
+            names += part
+        queries = ["zz", "yy", "qq", "zz " + names[3][3:], "yy " + names[per + 7][3:], "", "zz zz", "yy zz"]
+        cases = [(_lib.TOKEN_SET, 100, 64), (_lib.TOKEN_SET, 35, 10)]
+        os.environ["FUZZYHIP_NO_FUSED"] = "1"
+        exp = expected(names, queries, cases)
+        del os.environ["FUZZYHIP_NO_FUSED"]
+        run_threads(2, names, queries, cases, exp, want_fused=True, want_overflow={cases[0]})
         print("comm case ok:", mode)
         return
     names, queries = corpus_and_queries()

@@ -229,6 +229,22 @@ def test_topk_many_ties_walk(oracle, runner, tmp_path):
         assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == exp
 
 
+def test_topk_ties_far_into_the_list(oracle, runner, tmp_path):
+    """> SEL_TIECAP ties at the cut, all of them beyond the walk's budget (32 x 256 candidates): radix select over
+    the original indices; one block per row and several (FUZZYHIP_SELECT_SLICE)"""
+    cand = ["cc dd %d" % (i % 7) for i in range(8300)] + ["aa bb"] * 2500 + ["aa"] * 3
+    buf, o = oracle.pack(cand)
+    for env in (None, {"FUZZYHIP_SELECT_SLICE": "2048"}):
+        for k, ms in ((12, 35), (1, 100)):
+            idx, score, cnt = _run(runner, tmp_path, 2, 0, cand, ["aa bb", "cc dd"], min_score=ms, k=k, env=env)
+            for qi, q in enumerate(["aa bb", "cc dd"]):
+                exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, ms, k)
+                assert [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))] == exp, (env, k, ms, q)
+    idx, score, cnt = _run(runner, tmp_path, 2, 0 | 0x100, cand, ["aa"], min_score=100, k=5)
+    exp = [i for i, s_ in enumerate(cand) if oracle.score(oracle.TOKEN_SET, "aa", s_) >= 100][:5]
+    assert [int(idx[0, j]) for j in range(int(cnt[0]))] == exp
+
+
 def test_partial_ratio(oracle, runner, tmp_path):
     import random
     rnd = random.Random(23)

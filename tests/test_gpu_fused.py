@@ -149,11 +149,16 @@ def test_fused_list_overflow_falls_back(oracle, monkeypatch):
     with Corpus.from_prepared(cand) as c:
         got = c.topk(queries, 100, 64)
         t = c.timing()
-        assert t["fused"] == 1 and t["fused_fallback_chunks"] >= 1, t
+        assert t["fused"] == 1 and t["fused_fallback_chunks"] >= 1 and t["fused_fallback_rows"] == 1, t    # only the 'zz' row
         exp = _oracle_topk_rows(oracle, oracle.TOKEN_SET, queries, buf, o, 100, 64)
         g = _rows(*got)
         for qi, q in enumerate(queries):
             assert g[qi] == exp[qi], (q, g[qi][:4], exp[qi][:4])
+        # more overflowed rows than are redone one by one: the chunk goes through the matrix as a whole
+        many = c.topk(["zz"] * 300, 100, 64)
+        t = c.timing()
+        assert t["fused"] == 1 and t["fused_fallback_rows"] == 300, t
+        assert all(r == exp[0] for r in _rows(*many))
         # the same rows when nothing overflows (k below what the sample leaves): no fallback
         got = c.topk(queries[2:], 35, 10)
         assert c.timing()["fused_fallback_chunks"] == 0
@@ -168,3 +173,6 @@ def test_fused_sharded_exchange(monkeypatch):
     fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
     assert os.path.exists(fake)
     _run("threads_fused", {"FUZZYHIP_RCCL_LIB": fake, "FUZZYHIP_FUSED_MIN_MB": "0"})
+    # a shard whose fused lists overflow: its status word sends every rank round once more (no host synchronisation
+    # stands between the local step and the all-gather, so the overflow is only known afterwards)
+    _run("threads_overflow", {"FUZZYHIP_RCCL_LIB": fake, "FUZZYHIP_FUSED_MIN_MB": "0"})

@@ -65,6 +65,31 @@ def test_topk_order_under_ties(oracle):
             _check_topk(oracle, c, queries, cand, ms, k)
 
 
+def test_ties_clustered_far_into_the_list(oracle):
+    """The holders of a token that only one region of the list uses (a 10^8-name list read region by region): tens of
+    thousands of ties at 100 whose first original index is beyond any walk from 0.  One block per row (20 queries),
+    several per row (2 queries), and the sample rows of a fused call -- the radix select of fz_select_topk."""
+    cps, offs = synth.make_corpus(300_000, max_chars=32, seed=131, vocab_size=3000)
+    names = synth.to_strings(cps, offs)
+    for i in range(240_000, 290_000):
+        if i % 2:
+            names[i] = "qq7 " + names[i]
+    queries = ["qq7", "qq7 zz", names[240_001]] + synth.make_queries(cps, offs, 17, seed=132, max_chars=32)
+    buf, o = oracle.pack(names)
+    oracle.lib().orc_set_bitpar(1)
+    try:
+        with Corpus.from_prepared(names) as c:
+            for qs, k, ms in ((queries, 10, 35), (queries[:2], 64, 100), (queries * 12, 10, 35)):
+                idx, score, cnt = c.topk(qs, ms, k)
+                for qi in [q_ for q_ in (0, 1, 2, 5) if q_ < len(qs)]:
+                    exp = oracle.topk(oracle.TOKEN_SET, qs[qi], buf, o, ms, k)
+                    got = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
+                    assert got == exp, (len(qs), k, ms, qs[qi], got[:4], exp[:4])
+            assert c.timing()["fused"] == 1            # 240 rows x 300 032 = 72 MB: the last call was a fused one
+    finally:
+        oracle.lib().orc_set_bitpar(0)
+
+
 def test_edge_cases(oracle):
     cand = ["", "a", "a a a", "b a", "a b", "   ", "abc def", "def abc", "abc", "x" * 70, "ab " * 30,
             "coke 330ml 1x24 np sleek can", "coke sleek can", "fuzzy fuzzy was a bear"]

@@ -1,0 +1,10 @@
+set -e
+O=gpurun_out
+timeout -k 10 500 python -u -m pytest tests/test_gpu_fused.py tests/test_gpu_comm.py -x -q --timeout 300 --timeout-method thread > $O/r3t_tests.log 2>&1
+bash tools/sweep_env.sh r3t "X=1" "FUZZYHIP_STREAM_BLOCKS_SAMPLE=96" "FUZZYHIP_STREAM_BLOCKS_SAMPLE=48" "FUZZYHIP_STREAM_BLOCKS_SAMPLE=24"
+timeout -k 10 500 python bench.py --workload C3 --gpus 1 --candidates 12500032 --no-cpu-baseline --exchange rccl > $O/r3t_12500032.json 2> $O/r3t_12500032.err
+python - <<PY
+import json
+d=json.loads(open("$O/r3t_12500032.json").read().strip().splitlines()[-1])
+print("12.5M: step %.1f ms  score %.1f  select %.1f  value %.3e  redo rows %s exchange %s" % (d["ms_per_step"], d["kernel_ms_per_step"]["score"], d["kernel_ms_per_step"]["select"], d["value"], d["fused_rows_redone_through_matrix"], d.get("exchange",{}).get("all_gather_plus_device_merge_ms_per_step")))
+PY

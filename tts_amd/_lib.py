@@ -40,7 +40,7 @@ class FzTiming(ctypes.Structure):
                 ("score_launches", ctypes.c_uint32), ("select_launches", ctypes.c_uint32),
                 ("pairs", ctypes.c_uint64), ("host_prep_ms", ctypes.c_double),
                 ("fused", ctypes.c_uint32), ("fused_fallback_chunks", ctypes.c_uint32),
-                ("exchange_ms", ctypes.c_float), ("reserved", ctypes.c_uint32)]
+                ("exchange_ms", ctypes.c_float), ("fused_fallback_rows", ctypes.c_uint32)]
 
 
 # every symbol include/fuzzyhip.h declares: name -> (restype, argtypes)

@@ -207,5 +207,9 @@ struct FzMergeParams {
     uint32_t cap, k;
     uint64_t *out_keys;           // [rows][k]; may alias sample_keys
     uint32_t *out_cnt;            // [rows] or null
-    uint32_t *overflow;           // one counter: rows whose list ran past cap
+    uint32_t *overflow;           // one counter: rows (of this launch) whose list ran past cap
+    uint32_t *ovf_rows;           // [0]: rows that overflowed so far in the whole call, [1 + i]: their row numbers (first ovf_rows_cap of them)
+    uint32_t ovf_rows_cap;
+    uint32_t row_base;            // row number of this launch's row 0 within the call
 };
+#define FZ_FUSED_REDO_ROWS 256u    // up to this many overflowed rows of a call are redone one by one; more: whole chunks

@@ -217,6 +217,7 @@ struct fz_corpus {
     // sliced select (FzSelectParams::n_slices): a few rows over a large shard are selected by several blocks per row
     uint64_t *d_slice_keys = nullptr; uint32_t *d_slice_done = nullptr;
     uint32_t select_slice = 65536, select_slice_rows = 8;  // FUZZYHIP_SELECT_SLICE (positions per block, 0: off), rows up to which rows are sliced
+    uint32_t stream_blocks_sample = 48;                   // ... of the sample phase of a fused call (FUZZYHIP_STREAM_BLOCKS_SAMPLE)
     uint32_t stream_min_queries = 8;                      // FUZZYHIP_STREAM_MIN_QUERIES: smaller batches take the general kernel for every tile
     uint32_t stream_max_group = 1024;                     // most queries one work item takes (FUZZYHIP_STREAM_MAX_GROUP); its waves share them out
     std::vector<hipEvent_t> events;
@@ -227,6 +228,15 @@ struct fz_corpus {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> score, select;
         hipEvent_t first = nullptr, last = nullptr;
     } pending;
+    // an asynchronous fused call (fz_query_topk_sharded) leaves its overflow records in the workspace: which rows must be
+    // redone is only known once the caller has synchronised; redo_async_overflow() then repairs those rows
+    struct AsyncFused {
+        bool valid = false;
+        uint32_t *d_ovf = nullptr, *d_ovf_rows = nullptr;
+        uint32_t nchunks = 0; uint64_t rows_per_chunk = 0;
+        int view_kind = 0, kmode = 0; FzTies ties{0, 0};
+        uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr; int32_t min_score = 0; uint32_t k = 0, flat = 0;
+    } async_fused;
     std::mutex mu;
 };
 
@@ -635,6 +645,7 @@ static int finish_create(fz_corpus *c)
     if (const char *e = getenv("FUZZYHIP_SLAB_KB")) c->slab_bytes = (uint64_t)std::max(1, atoi(e)) << 10;
     if (const char *e = getenv("FUZZYHIP_STREAM_WAVES")) c->stream_waves = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("FUZZYHIP_STREAM_BLOCKS")) c->stream_blocks = (uint32_t)std::max(1, atoi(e));
+    if (const char *e = getenv("FUZZYHIP_STREAM_BLOCKS_SAMPLE")) c->stream_blocks_sample = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("FUZZYHIP_STREAM_MAX_GROUP")) c->stream_max_group = (uint32_t)std::max(32, atoi(e));
     {
         hipDeviceProp_t prop;
@@ -1558,7 +1569,8 @@ static int launch_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, cons
             p.nq = (uint32_t)b.qrec.size();
             // enough blocks to balance the chip, enough queries per block to amortise the tile set-up
             const uint64_t bx = (units + 15u) / 16u;
-            uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (c->stream_blocks + bx - 1) / bx));
+            const uint32_t want_blocks = ph == PH_SAMPLE ? c->stream_blocks_sample : c->stream_blocks;
+            uint64_t by = std::max<uint64_t>(1, std::min<uint64_t>((p.nq + 31) / 32, (want_blocks + bx - 1) / bx));
             // ... and no item so long that the launch ends in a tail of it (a large batch over a large shard)
             by = std::max<uint64_t>(by, (p.nq + c->stream_max_group - 1) / c->stream_max_group);
             p.q_per_block = (uint32_t)((p.nq + by - 1) / by);
@@ -1715,6 +1727,44 @@ static int run_matrix(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_off
     return FZ_OK;
 }
 
+// Lists that overflowed (more than FZ_EMIT_CAP candidates reached the sample's limit: hits clustered in index or length
+// where the sample tiles happen not to fall).  Up to FZ_FUSED_REDO_ROWS such rows are redone one by one through the
+// score matrix -- a row writes its own keys, the others stay --, more than that chunk by chunk.  Results are the
+// same either way.  The stream has been synchronised by the caller.
+static int redo_overflow(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq, int view_kind, int kmode,
+                         FzTies ties, const TopkTarget &t, RunMode mode, RunOut &o, CallEvents &ev, hipStream_t st,
+                         const uint32_t *d_ovf, const uint32_t *d_ovf_rows, uint32_t nchunks, uint64_t rows_per_chunk)
+{
+    int rc;
+    std::vector<uint32_t> h_ovf(nchunks, 0u), h_rows(1u + FZ_FUSED_REDO_ROWS, 0u);
+    HIP_TRY(hipMemcpy(h_ovf.data(), d_ovf, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
+    bool any = false;
+    for (uint32_t x : h_ovf) any |= x != 0u;
+    if (!any) return FZ_OK;
+    HIP_TRY(hipMemcpy(h_rows.data(), d_ovf_rows, h_rows.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t x : h_ovf) c->timing.fused_fallback_chunks += x != 0u ? 1u : 0u;
+    if (h_rows[0] <= FZ_FUSED_REDO_ROWS) {
+        std::sort(h_rows.begin() + 1, h_rows.begin() + 1 + h_rows[0]);
+        if (getenv("FUZZYHIP_TRACE")) fprintf(stderr, "fuzzyhip: %u rows overflowed their lists; redone one by one through the score matrix\n", h_rows[0]);
+        c->timing.fused_fallback_rows = h_rows[0];
+        for (uint32_t i = 0; i < h_rows[0]; ++i) {
+            const uint64_t r = h_rows[1u + i];
+            if (r >= nq) return fail(FZ_ERR_INVALID, "internal: overflowed row %llu of %u", (unsigned long long)r, nq);
+            if ((rc = run_matrix(c, q_cps, q_offs, r, r + 1, view_kind, kmode, ties, mode, o, t, ev, st)) != FZ_OK) return rc;
+        }
+        return FZ_OK;
+    }
+    uint32_t ci = 0;
+    for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk, ++ci) {
+        if (h_ovf[ci] == 0u) continue;
+        if (getenv("FUZZYHIP_TRACE")) fprintf(stderr, "fuzzyhip: %u rows of chunk %u overflowed their lists; chunk redone through the score matrix\n", h_ovf[ci], ci);
+        c->timing.fused_fallback_rows += h_ovf[ci];
+        const uint64_t qb = std::min<uint64_t>(nq, q0 + rows_per_chunk);
+        if ((rc = run_matrix(c, q_cps, q_offs, q0, qb, view_kind, kmode, ties, mode, o, t, ev, st)) != FZ_OK) return rc;
+    }
+    return FZ_OK;
+}
+
 // Fused threshold + top-k (FzEmit, fz_common.h): sample tiles -> small score matrix -> fz_select_topk fixes
 // each row's limit -> the other tiles append the keys that reach it -> fz_merge_lists.  No score matrix
 // over the whole shard, so a batch is not cut to fit one.  A chunk whose lists overflowed is redone
@@ -1732,7 +1782,7 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
     const uint32_t cap = FZ_EMIT_CAP;
     auto a256 = [](uint64_t x) { return (x + 255ull) & ~255ull; };
     // arena (the workspace's score buffer): [overflow counters][per chunk: limits | counts | lists | sample scores]
-    const uint64_t ovf_bytes = a256((uint64_t)FZ_FUSED_MAX_CHUNKS * 4);
+    const uint64_t ovf_bytes = a256((uint64_t)FZ_FUSED_MAX_CHUNKS * 4) + a256((uint64_t)(1u + FZ_FUSED_REDO_ROWS) * 4);   // chunk counters | overflowed rows
     const uint64_t per_row = ns_pad + (uint64_t)cap * 8 + 8 + 4;
     const uint64_t budget = w.fixed ? w.scores_cap : std::max<uint64_t>(c->ws_limit, ovf_bytes + per_row + 1024);
     if (budget < ovf_bytes + per_row + 1024)
@@ -1747,12 +1797,14 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
     const uint64_t arena = o_sc + a256(rows_per_chunk * ns_pad);
     if ((rc = ensure(w, &w.d_scores, &w.scores_cap, (size_t)arena, "fused top-k workspace")) != FZ_OK) return rc;
     uint32_t *d_ovf = reinterpret_cast<uint32_t *>(w.d_scores);
+    uint32_t *d_ovf_rows = reinterpret_cast<uint32_t *>(w.d_scores + a256((uint64_t)FZ_FUSED_MAX_CHUNKS * 4));
     uint64_t *d_lim = reinterpret_cast<uint64_t *>(w.d_scores + o_lim);
     uint32_t *d_ecnt = reinterpret_cast<uint32_t *>(w.d_scores + o_cnt);
     uint64_t *d_list = reinterpret_cast<uint64_t *>(w.d_scores + o_list);
     uint8_t *d_sc = w.d_scores + o_sc;
     const uint32_t nchunks = (uint32_t)((nq + rows_per_chunk - 1) / rows_per_chunk);
     HIP_TRY(hipMemsetAsync(d_ovf, 0, (size_t)nchunks * 4, st));
+    HIP_TRY(hipMemsetAsync(d_ovf_rows, 0, 4, st));
 
     uint32_t ci = 0;
     for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk, ++ci) {
@@ -1779,6 +1831,7 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
         FzMergeParams mp{};
         mp.sample_keys = t.d_keys + q0 * t.k; mp.list = d_list; mp.cnt = d_ecnt; mp.cap = cap; mp.k = t.k;
         mp.out_keys = t.d_keys + q0 * t.k; mp.out_cnt = t.d_cnt ? t.d_cnt + q0 : nullptr; mp.overflow = d_ovf + ci;
+        mp.ovf_rows = d_ovf_rows; mp.ovf_rows_cap = FZ_FUSED_REDO_ROWS; mp.row_base = (uint32_t)q0;
         HIP_TRY(fz_launch_merge(mp, rows, st));
         if ((rc = ev.mark(&e4, st)) != FZ_OK) return rc;
         ev.score.push_back({e0, e1}); ev.score.push_back({e2, e3});
@@ -1787,34 +1840,27 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
         c->timing.pairs += (uint64_t)rows * c->n;
     }
     if (mode == RUN_TOPK_DEVICE && !o.sync) {
-        // asynchronous caller: no host look at the counters; they are folded into its status word on the stream
+        // asynchronous caller: no host look at the counters; they are folded into its status word on the stream, and the
+        // caller repairs the overflowed rows after its own synchronisation (redo_async_overflow)
         HIP_TRY(fz_launch_fold_status(d_ovf, nchunks, o.d_status, st));
+        fz_corpus::AsyncFused &a = c->async_fused;
+        a.valid = true; a.d_ovf = d_ovf; a.d_ovf_rows = d_ovf_rows; a.nchunks = nchunks; a.rows_per_chunk = rows_per_chunk;
+        a.view_kind = view_kind; a.kmode = kmode; a.ties = ties;
+        a.d_keys = t.d_keys; a.d_cnt = t.d_cnt; a.min_score = t.min_score; a.k = t.k; a.flat = t.flat;
         return FZ_OK;
     }
-    // lists that overflowed (an adversarial order of arrival; none in any workload measured): redo those chunks
-    std::vector<uint32_t> h_ovf(nchunks, 0u);
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(h_ovf.data(), d_ovf, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
-    ci = 0;
-    for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk, ++ci) {
-        if (h_ovf[ci] == 0u) continue;
-        if (getenv("FUZZYHIP_TRACE")) fprintf(stderr, "fuzzyhip: %u rows of chunk %u overflowed their lists; chunk redone through the score matrix\n", h_ovf[ci], ci);
-        c->timing.fused_fallback_chunks++;
-        const uint64_t qb = std::min<uint64_t>(nq, q0 + rows_per_chunk);
-        if ((rc = run_matrix(c, q_cps, q_offs, q0, qb, view_kind, kmode, ties, mode, o, t, ev, st)) != FZ_OK) return rc;
-    }
-    return FZ_OK;
+    return redo_overflow(c, q_cps, q_offs, nq, view_kind, kmode, ties, t, mode, o, ev, st, d_ovf, d_ovf_rows, nchunks, rows_per_chunk);
 }
 
-static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
-                       int view_kind, int kmode, FzTies ties, int32_t min_score, uint32_t k,
-                       RunMode mode, RunOut &o, Workspace *fixed_ws = nullptr)
+// c->mu held by the caller
+static int run_queries_locked(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                              int view_kind, int kmode, FzTies ties, int32_t min_score, uint32_t k,
+                              RunMode mode, RunOut &o, Workspace *fixed_ws = nullptr)
 {
-    if (!c) return fail(FZ_ERR_INVALID, "null corpus");
     if (nq && (!q_offs || (!q_cps && q_offs[nq] != q_offs[0]))) return fail(FZ_ERR_INVALID, "null query buffers");
     const bool topk = mode == RUN_TOPK_HOST || mode == RUN_TOPK_DEVICE;
     if (topk && k > FZ_MAX_K) return fail(FZ_ERR_LIMIT, "k=%u exceeds FZ_MAX_K=%u", k, FZ_MAX_K);
-    std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if (fixed_ws && !c->views[view_kind].built)
@@ -1832,6 +1878,7 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     Workspace &w = *c->ws;
     c->timing = fz_timing{};
     c->pending.valid = false;
+    c->async_fused.valid = false;
 
     const bool nothing = topk && (k == 0 || c->n == 0 || min_score > 100);
     uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr;
@@ -1892,6 +1939,35 @@ static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_of
     for (auto &s : ev.score) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.score_ms += ms; }
     for (auto &s : ev.select) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.select_ms += ms; }
     { float ms = 0; if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) c->timing.total_ms = ms; }
+    return FZ_OK;
+}
+
+static int run_queries(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                       int view_kind, int kmode, FzTies ties, int32_t min_score, uint32_t k,
+                       RunMode mode, RunOut &o, Workspace *fixed_ws = nullptr)
+{
+    if (!c) return fail(FZ_ERR_INVALID, "null corpus");
+    std::lock_guard<std::mutex> lk(c->mu);
+    return run_queries_locked(c, q_cps, q_offs, nq, view_kind, kmode, ties, min_score, k, mode, o, fixed_ws);
+}
+
+// The rows of the last asynchronous fused call whose lists overflowed, redone (synchronously) into the call's key
+// buffer; the stream has been synchronised since the call and nothing else has used the corpus (c->mu held throughout).
+static int redo_async_overflow(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq)
+{
+    fz_corpus::AsyncFused &a = c->async_fused;
+    if (!a.valid) return FZ_OK;
+    a.valid = false;
+    HIP_TRY(hipSetDevice(c->device));
+    CallEvents ev{c, false};
+    RunOut o; o.d_keys = a.d_keys; o.d_cnt = a.d_cnt; o.sync = 1; o.flat = a.flat;
+    const TopkTarget t{a.d_keys, a.d_cnt, a.min_score, a.k, a.flat};
+    int rc = redo_overflow(c, q_cps, q_offs, nq, a.view_kind, a.kmode, a.ties, t, RUN_TOPK_DEVICE, o, ev, c->stream,
+                           a.d_ovf, a.d_ovf_rows, a.nchunks, a.rows_per_chunk);
+    if (rc != FZ_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &s : ev.score) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.score_ms += ms; }
+    for (auto &s : ev.select) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.select_ms += ms; }
     return FZ_OK;
 }
 
@@ -2300,8 +2376,8 @@ static int fz_comm_create_impl(const void *id, int n_ranks, int rank, int device
 // the collective whatever happened to its local step: a status word travels behind each rank's keys (0 ok, 1
 // the local step failed -- its keys are zeroed --, 2 a fused list overflowed, so the keys are not final).  After
 // the one synchronisation at the end every rank knows the worst status: on 1 all ranks return an error (the
-// failing rank its own), on 2 all ranks go round once more, the overflowed ones with their local step redone
-// synchronously (which repairs overflowed chunks through the score matrix), the others with the keys they have.
+// failing rank its own), on 2 all ranks go round once more, the overflowed ones after redoing the rows whose lists
+// overflowed through the score matrix (redo_async_overflow), the others with the keys they have.
 hipError_t fz_launch_merge_gathered_strided(const uint64_t *all, uint64_t list_stride, uint32_t n_lists, uint32_t nq, uint32_t k,
                                             uint64_t *out, uint64_t *status_out, hipStream_t st);
 
@@ -2324,29 +2400,32 @@ static int fz_query_topk_sharded_impl(fz_corpus *c, fz_comm *cm, const uint32_t 
     // argument errors are the same on every rank (same queries, scorer, k): returning here leaves no peer waiting
     if ((rc = scorer_plan(scorer & 0xFF, &view, &kmode, &ties)) != FZ_OK) return rc;
     std::lock_guard<std::mutex> lk(cm->mu);
+    std::lock_guard<std::mutex> lc(c->mu);                          // the corpus' stream, workspace and timing record, for the whole call
     HIP_TRY(hipSetDevice(cm->device));
     const size_t nkeys = (size_t)nq * k, words = nkeys + 1;
     if ((rc = comm_reserve(cm, words)) != FZ_OK) return rc;         // grows only beyond what fz_comm_create reserved
     uint64_t *d_status = cm->d_local + nkeys;
+    hipStream_t st = c->stream;
     float exchange_ms = 0.f;
-    bool redo_sync = false;
+    bool redo = false;
     for (int round = 0; round < 2; ++round) {
         int local_rc = FZ_OK;
         std::string local_err;
-        if (round == 0 || redo_sync) {
-            RunOut o; o.d_keys = cm->d_local; o.d_cnt = nullptr; o.sync = redo_sync ? 1 : 0; o.d_status = d_status;
+        if (round == 0) {
+            RunOut o; o.d_keys = cm->d_local; o.d_cnt = nullptr; o.sync = 0; o.d_status = d_status;
             o.flat = (scorer & FZ_ORDER_BY_INDEX) ? 1u : 0u;
-            local_rc = run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_DEVICE, o);
-            if (local_rc != FZ_OK) local_err = g_err;
+            local_rc = run_queries_locked(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_DEVICE, o);
+        } else if (redo) {
+            local_rc = redo_async_overflow(c, q_cps, q_offs, nq);    // only the rows whose lists overflowed
         }
-        std::lock_guard<std::mutex> lc(c->mu);                      // the corpus' stream and timing record
-        hipStream_t st = c->stream;
+        if (local_rc != FZ_OK) local_err = g_err;
+        st = c->stream;
         if (local_rc != FZ_OK) {
             // still enter the collective, with no keys and status 1: the peers must not wait for this rank for ever
             HIP_TRY(hipMemsetAsync(cm->d_local, 0, words * 8, st));
             HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_status), 1, 1, st));
         } else if (round == 1) {
-            HIP_TRY(hipMemsetAsync(d_status, 0, 8, st));            // keys are final now (redone, or never in doubt)
+            HIP_TRY(hipMemsetAsync(d_status, 0, 8, st));            // keys are final now (rows redone, or never in doubt)
         }
         HIP_TRY(hipEventRecord(cm->ev0, st));
         RCCL_TRY(rccl::g_api.all_gather(cm->d_local, cm->d_all, words, rccl::kUint64, cm->comm, st));
@@ -2363,7 +2442,7 @@ static int fz_query_topk_sharded_impl(fz_corpus *c, fz_comm *cm, const uint32_t 
         if (worst == 1ull) return fail(FZ_ERR_COMM, "another rank failed in its local top-k step (its own call returns the cause); no result");
         if (worst == 0ull) break;
         if (round == 1) return fail(FZ_ERR_COMM, "a rank reported unfinished keys twice");
-        redo_sync = mine == 2ull;                                   // worst == 2: one more round, on every rank
+        redo = mine == 2ull;                                        // worst == 2: one more round, on every rank
     }
     decode_keys(cm->h_out, nq, k, out_idx, out_score, out_cnt);
     return FZ_OK;

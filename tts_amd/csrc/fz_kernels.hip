@@ -1310,6 +1310,7 @@ hipError_t fz_launch_stream(int W, int mode, const FzStreamParams &p, hipStream_
 // ---------------------------------------------------------------------------------------------
 #define SEL16_THREADS 256u     // fz_select16_topk: one thread per histogram bin
 #define SEL_TIECAP 2048u
+#define SEL_WALK_STEPS 32u    // steps of the walk in original order before the radix select takes over
 #define SEL_PICK_MAX 16u      // up to this many ties are picked by repeated minima instead of a sort
 #define SEL_VEC 4u            // 16-byte vectors per thread per iteration of the row passes
 
@@ -1568,11 +1569,13 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
                 fz_bitonic<uint32_t, false>(s_ties, P);
             }
         } else {
-            // many ties: walk candidates in ORIGINAL order and keep the first `need` tied ones
-            uint32_t found = 0u;
+            // many ties: walk candidates in ORIGINAL order and keep the first `need` tied ones.  Where ties are dense from
+            // the start of the list (a one-token query that a third of the names contain) that takes one or two steps.
+            uint32_t found = 0u, o0 = 0u;
             // (a sample row walks the sample's own list of original indices, ascending, not all of the shard's)
             const uint32_t n_walk = p.walk ? n : p.n_orig;
-            for (uint32_t o0 = 0u; o0 < n_walk && found < need; o0 += THREADS) {
+            const uint32_t budget = SEL_WALK_STEPS * THREADS;
+            for (; o0 < n_walk && found < need && o0 < budget; o0 += THREADS) {
                 const uint32_t wi = o0 + tid;
                 const uint32_t o = wi < n_walk ? (p.walk ? p.walk[wi] : wi) : 0xFFFFFFFFu;
                 bool pred = false;
@@ -1591,6 +1594,77 @@ __global__ __launch_bounds__(THREADS, 8) void fz_select_topk(FzSelectParams p)
                 const uint32_t mine = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                 if (pred && mine < need) s_ties[mine] = o;
                 for (uint32_t w = 0; w < (THREADS / 64u); ++w) found += s_misc[16 + w];
+                __syncthreads();
+            }
+            if (found < need && o0 < n_walk) {
+                // The ties lie far into the list (the holders of a token that only one region of the list uses: the walk
+                // would pass millions of candidates first).  Radix select instead: the need-th smallest original index X
+                // among the ties, 11 bits per pass over this block's scores with a histogram in s_ties, then the ties with
+                // index <= X -- exactly `need` of them, indices being distinct -- are collected.  Independent of where the
+                // ties sit; a pass costs one read of the block's scores plus one index load and one LDS add per tie.
+                auto scan_ties = [&](auto &&fn) {
+                    const uint32_t addq = 0x01010101u * (128u - (sstar ? sstar : 1u));
+                    for (uint32_t v0 = 0u; v0 < nv; ++v0) {
+                        const uint32_t base = (v0 * THREADS + tid) * 16u;
+                        if (base >= n) break;
+                        const uint32_t pb = FZ_SEL_PHYS(base);
+                        const uint4 vq = *reinterpret_cast<const uint4 *>(sc + pb);
+                        const uint32_t wv[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            uint32_t m = sstar != 0u ? (((wv[a] + addq) | wv[a]) & 0x80808080u) : 0x80808080u;
+                            while (m != 0u) {
+                                const uint32_t sh = (uint32_t)__builtin_ctz(m) - 7u;
+                                m &= m - 1u;
+                                const uint32_t sv = (wv[a] >> sh) & 0xFFu;
+                                const uint32_t ph = pb + (uint32_t)(4 * a) + (sh >> 3);
+                                if (ph < p.n && (p.flat ? (sv >= sstar && sv <= 100u) : (sv == sstar))) fn(orig_of_phys[ph]);
+                            }
+                        }
+                    }
+                };
+                const uint32_t total_bits = p.n_orig > 1u ? 32u - (uint32_t)__builtin_clz(p.n_orig - 1u) : 1u;
+                uint32_t hi = total_bits, prefix = 0u, remaining = need;
+                while (hi > 0u) {
+                    const uint32_t lo_b = hi > 11u ? hi - 11u : 0u, nb = 1u << (hi - lo_b);
+                    for (uint32_t i = tid; i < nb; i += THREADS) s_ties[i] = 0u;
+                    __syncthreads();
+                    const bool first = hi == total_bits;
+                    scan_ties([&](uint32_t o) {
+                        if (first || (o >> hi) == prefix) atomicAdd(&s_ties[(o >> lo_b) & (nb - 1u)], 1u);
+                    });
+                    __syncthreads();
+                    if (wave == 0u) {
+                        // the bin where the running count reaches `remaining`: each lane sums a run of bins, a wave
+                        // scan finds the run, its lane walks it
+                        const uint32_t per = nb >= 64u ? nb / 64u : 1u;
+                        uint32_t sum = 0u;
+                        for (uint32_t j = 0u; j < per; ++j) { const uint32_t b_ = lane * per + j; if (b_ < nb) sum += s_ties[b_]; }
+                        uint32_t cum = sum;
+                        for (uint32_t off = 1u; off < 64u; off <<= 1) {
+                            const uint32_t t_ = (uint32_t)__shfl((int)cum, (int)(lane >= off ? lane - off : lane), 64);
+                            if (lane >= off) cum += t_;
+                        }
+                        const uint64_t reach = __ballot(cum >= remaining);      // non-empty: the ties number at least `need`
+                        const uint32_t who = reach != 0ull ? (uint32_t)__builtin_ctzll(reach) : 63u;
+                        if (lane == who) {
+                            uint32_t below = cum - sum, b_ = lane * per;
+                            for (uint32_t j = 0u; j + 1u < per && below + s_ties[b_] < remaining; ++j) { below += s_ties[b_]; ++b_; }
+                            s_misc[4] = b_; s_misc[5] = below;
+                        }
+                    }
+                    __syncthreads();
+                    prefix = (prefix << (hi - lo_b)) | s_misc[4];
+                    remaining -= s_misc[5];
+                    hi = lo_b;
+                    __syncthreads();
+                }
+                if (tid == 0u) s_misc[3] = 0u;
+                __syncthreads();
+                const uint32_t X = prefix;
+                scan_ties([&](uint32_t o) {
+                    if (o <= X) { const uint32_t pos = atomicAdd(&s_misc[3], 1u); if (pos < need) s_ties[pos] = o; }
+                });
                 __syncthreads();
             }
         }
@@ -1683,7 +1757,13 @@ __global__ __launch_bounds__(256) void fz_merge_lists(FzMergeParams p)
     const uint32_t tid = threadIdx.x, row = blockIdx.x, k = p.k;
     const uint32_t cnt = p.cnt[row];
     const uint32_t nl = cnt < p.cap ? cnt : p.cap;
-    if (cnt > p.cap && tid == 0u) atomicAdd(p.overflow, 1u);          // the host redoes the chunk through the score matrix
+    if (cnt > p.cap && tid == 0u) {                                   // the host redoes the row (or the chunk) through the score matrix
+        atomicAdd(p.overflow, 1u);
+        if (p.ovf_rows != nullptr) {
+            const uint32_t at = atomicAdd(&p.ovf_rows[0], 1u);
+            if (at < p.ovf_rows_cap) p.ovf_rows[1u + at] = p.row_base + row;
+        }
+    }
     const uint32_t total = k + nl;
     uint32_t P = 2u;
     while (P < total) P <<= 1;
