@@ -354,6 +354,26 @@ def main():
         fused_steps += t["fused"]; fallback_chunks += t["fused_fallback_chunks"]; fallback_rows += t["fused_fallback_rows"]
     fence()
     elapsed = time.perf_counter() - t0
+    # The same K steps as a queue of batches: fz_query_topk_submit / fz_query_topk_wait with two batches in flight, so
+    # that the host work of step i+1 (query tables, Python, decoding of step i-1) passes under the kernels of step i.
+    # Every step is a whole call (tables, upload, kernels, copy back, decode) inside the fences; results are compared
+    # with the synchronous loop's.
+    piped = None
+    if world == 1 and comm is None and args.steps >= 2 and not os.environ.get("FUZZYHIP_BENCH_NO_PIPELINE"):
+        for _ in range(min(args.warmup, 2)):
+            corpus.topk_wait(corpus.topk_submit(q_packed, min_score, k))
+        fence()
+        t0 = time.perf_counter()
+        prev, last_p = None, None
+        for _ in range(args.steps):
+            tk = corpus.topk_submit(q_packed, min_score, k)
+            if prev is not None:
+                last_p = corpus.topk_wait(prev)
+            prev = tk
+        last_p = corpus.topk_wait(prev)
+        fence()
+        elapsed_p = time.perf_counter() - t0
+        piped = {"elapsed": elapsed_p, "equal": bool(all((a == b).all() for a, b in zip(last, last_p)))}
     alg_local = float(synth.algorithmic_bytes_per_query(info))
     if world > 1:
         dev = "cpu"
@@ -368,6 +388,13 @@ def main():
 
     pairs_per_step = float(nq) * n_all
     value = pairs_per_step * args.steps / elapsed
+    sync_line = None
+    if piped and piped["equal"] and piped["elapsed"] < elapsed:
+        # the headline is the job's throughput with two batches in flight; the one-call-at-a-time figures stay beside it
+        sync_line = {"value": value, "ms_per_step": elapsed / args.steps * 1e3,
+                     "calls": "fz_query_topk: one synchronous call per step (the reference's calling convention)"}
+        elapsed = piped["elapsed"]
+        value = pairs_per_step * args.steps / elapsed
 
     out = None
     if rank == 0:
@@ -433,7 +460,9 @@ def main():
                            "C3": f"C3: {nq} queries x {n_all} candidates in ONE corpus sharded over {world} GPU(s) by contiguous index ranges ({n_local}/GPU, <= {args.max_chars} chars), all-gather top-{k}, threshold {args.threshold}",
                            "C4": f"C4: {nq} queries x {n_local} candidates/GPU (8-60 tokens, <= {args.max_chars} chars, multi-word patterns), top-{k}, threshold {args.threshold}"}[wl],
                        "workload_id": wl, "max_chars": args.max_chars, "queries": nq, "candidates_per_gpu": n_local, "candidates_total": n_all, "k": k, "min_score": min_score,
-                       "parallelism": (f"shard{world}" if world > 1 else "single") + ("-rehearsal-gloo" if rehearsal else "")},
+                       "parallelism": (f"shard{world}" if world > 1 else "single") + ("-rehearsal-gloo" if rehearsal else ""),
+                       "calls": ("fz_query_topk_submit / fz_query_topk_wait, two batches in flight (every step a whole call: tables, "
+                                 "upload, kernels, copy back, decode)") if sync_line else "one synchronous call per step"},
             "roofline": roof,
             "roofline_hbm": hbm,
             "kernel_ms_per_step": {"score": score_ms / steps, "select": select_ms / steps, "host_query_prep": prep_ms / steps},
@@ -446,6 +475,12 @@ def main():
             "source_hash": source_hash(),
             "runtime": _lib.runtime_paths(),      # the HIP runtime the library is bound to, the librccl it opened
         }
+        if sync_line:
+            out["synchronous_calls"] = sync_line
+            out["two_in_flight_results_equal_synchronous"] = True
+        elif piped:
+            out["two_in_flight"] = {"ms_per_step": piped["elapsed"] / args.steps * 1e3, "results_equal_synchronous": piped["equal"],
+                                    "note": "not the headline: not faster than one call at a time, or results differed"}
         if world > 1:
             # the honest denominator of "x times 1 GPU": the SAME workload on one GPU, measured once and committed
             one = load_json("c3_1gpu_current.json")

@@ -59,6 +59,7 @@ typedef enum {
 #define FZ_MAX_K 1024u            /* top-k size */
 #define FZ_MAX_PATTERN 1024u      /* query pattern length in code points incl. token separators */
 #define FZ_MAX_CAND_LEN 16000u    /* canonical candidate length in code points */
+#define FZ_MAX_IN_FLIGHT 2u       /* fz_query_topk_submit tickets of one corpus not yet fetched */
 
 /* fz_query_topk_noalloc: size of the library's static device scratch array (held by every GPU the library
  * runs on until the process ends) and of the pinned host staging each corpus sets aside at creation */
@@ -172,6 +173,28 @@ int fz_set_workspace_limit(fz_corpus *c, uint64_t bytes);
 int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                   int scorer, int32_t min_score, uint32_t k, uint64_t *out_idx, int32_t *out_score,
                   uint32_t *out_cnt);
+
+/*
+ * fz_query_topk_submit / fz_query_topk_wait -- fz_query_topk in two phases, for callers that have the next batch ready
+ * while the GPU still works on this one (a serving loop over a queue of batches).  The reference's call is synchronous
+ * (src/fuzzy_search.py:16-38) and so is fz_query_topk; these two add nothing to its semantics.  submit builds the query
+ * tables, enqueues the upload, every kernel and the copy of the result on the corpus' stream and returns a ticket without
+ * waiting for the GPU; wait blocks until that call's result has arrived and decodes it into the caller's arrays (same
+ * meaning and order as fz_query_topk's, bit for bit).  Between them the host is free: the table building of call i+1
+ * (0.13 ms per 1000 queries) and the decoding of call i-1 pass under the kernels of call i.  A submit that finds the
+ * GPU busy with the call before it builds its tables and stops there; the wait that sees that earlier call finish
+ * enqueues it before decoding (FUZZYHIP_SUBMIT_EAGER=1: enqueue at once, behind the running kernels -- no host turn
+ * between calls, but the HIP runtime of the PyTorch wheels stalls in such launches).
+ *   - at most FZ_MAX_IN_FLIGHT tickets per corpus (a further submit fails with FZ_ERR_LIMIT); every ticket must be
+ *     waited for exactly once, in any order; fz_corpus_destroy waits for the GPU but fetches nothing
+ *   - q_cps / q_offs must stay valid and unchanged until the wait: rows whose fused lists overflow are redone from them
+ *   - calls of one corpus run on its one stream in the order they were submitted; other entry points may be called
+ *     in between (they queue up behind); fz_set_stream must not be called while a ticket is outstanding
+ *   - fz_last_timing after a wait describes the call most recently SUBMITTED, once it has finished
+ */
+int fz_query_topk_submit(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                         int scorer, int32_t min_score, uint32_t k, int *ticket);
+int fz_query_topk_wait(fz_corpus *c, int ticket, uint64_t *out_idx, int32_t *out_score, uint32_t *out_cnt);
 
 /*
  * fz_query_topk_noalloc -- fz_query_topk for callers that cannot allocate device memory while they run:

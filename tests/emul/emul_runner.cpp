@@ -5,11 +5,13 @@
 //   op 0 fz_score_all -> u8[nq*n];  op 1 fz_distance_all -> u16[nq*n];
 //   op 2 fz_query_topk -> u64 idx[nq*k], i32 score[nq*k], u32 cnt[nq]
 //   op 4 fz_corpus_save + fz_corpus_load, then fz_score_all on the loaded corpus -> u8[nq*n]
+//   op 5 fz_query_topk_submit x 2 (the batch, then its first half) + a refused third, waits in reverse order -> as op 2
 //   op 3 fz_query_topk_pair (scorer a | scorer b << 8; second corpus, queries and rank table appended) -> as op 2
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -83,6 +85,47 @@ int main(int argc, char **argv)
                                 (uint32_t)nq, rank_tab.data(), (uint32_t)h[3], (uint32_t)k, idx.data(), rk.data(), cnt.data());
         if (rc == FZ_OK) { fwrite(idx.data(), 8, nq * k, o); fwrite(rk.data(), 4, nq * k, o); fwrite(cnt.data(), 4, nq, o); }
         fz_corpus_destroy(cb);
+    } else if (op == 5) {
+        // two calls in flight: the whole batch (ticket a) and its first half (ticket b); a third submit is refused; b is
+        // fetched first; b's rows must be a's
+        std::vector<uint64_t> idx(nq * k ? nq * k : 1), idx_b(idx.size(), ~0ull);
+        std::vector<int32_t> sc(nq * k ? nq * k : 1), sc_b(sc.size(), -1);
+        std::vector<uint32_t> cnt(nq ? nq : 1), cnt_b(cnt.size(), ~0u);
+        const uint32_t nb = (uint32_t)(nq / 2);
+        int ta = -1, tb = -1, tc = -1;
+        rc = fz_query_topk_submit(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, min_score, (uint32_t)k, &ta);
+        if (rc == FZ_OK) rc = fz_query_topk_submit(c, qcps.data(), qoffs.data(), nb, (int)sk, min_score, (uint32_t)k, &tb);
+        if (rc == FZ_OK && fz_query_topk_submit(c, qcps.data(), qoffs.data(), nb, (int)sk, min_score, (uint32_t)k, &tc) != FZ_ERR_LIMIT) {
+            fprintf(stderr, "a third call in flight was accepted\n"); return 4;
+        }
+        if (rc == FZ_OK) rc = fz_query_topk_wait(c, tb, idx_b.data(), sc_b.data(), cnt_b.data());
+        if (rc == FZ_OK) rc = fz_query_topk_wait(c, ta, idx.data(), sc.data(), cnt.data());
+        if (rc == FZ_OK && fz_query_topk_wait(c, ta, idx.data(), sc.data(), cnt.data()) == FZ_OK) { fprintf(stderr, "a ticket was fetched twice\n"); return 4; }
+        if (rc == FZ_OK) {
+            for (uint32_t q = 0; q < nb; ++q) {
+                bool same = cnt_b[q] == cnt[q];
+                for (uint64_t j = 0; same && j < k; ++j) same = idx_b[q * k + j] == idx[q * k + j] && sc_b[q * k + j] == sc[q * k + j];
+                if (!same) { fprintf(stderr, "row %u of the second call in flight differs from the first call's\n", q); return 4; }
+            }
+            // the slots are free again; this time in submission order: the second call has only its tables built when the
+            // first one's wait sees the GPU free and sends it out
+            std::vector<uint64_t> idx_c(idx.size(), ~0ull); std::vector<int32_t> sc_c(sc.size(), -1); std::vector<uint32_t> cnt_c(cnt.size(), ~0u);
+            int td = -1;
+            rc = fz_query_topk_submit(c, qcps.data(), qoffs.data(), (uint32_t)nq, (int)sk, min_score, (uint32_t)k, &tc);
+            if (rc == FZ_OK) rc = fz_query_topk_submit(c, qcps.data(), qoffs.data(), nb, (int)sk, min_score, (uint32_t)k, &td);
+            if (rc == FZ_OK) rc = fz_query_topk_wait(c, tc, idx_c.data(), sc_c.data(), cnt_c.data());
+            std::fill(idx_b.begin(), idx_b.end(), ~0ull);
+            if (rc == FZ_OK) rc = fz_query_topk_wait(c, td, idx_b.data(), sc_b.data(), cnt_b.data());
+            if (rc == FZ_OK) {
+                bool same = idx_c == idx && sc_c == sc && cnt_c == cnt;
+                for (uint32_t q = 0; same && q < nb; ++q) {
+                    same = cnt_b[q] == cnt[q];
+                    for (uint64_t j = 0; same && j < k; ++j) same = idx_b[q * k + j] == idx[q * k + j] && sc_b[q * k + j] == sc[q * k + j];
+                }
+                if (!same) { fprintf(stderr, "the second round of calls in flight gave other results\n"); return 4; }
+            }
+        }
+        if (rc == FZ_OK) { fwrite(idx.data(), 8, nq * k, o); fwrite(sc.data(), 4, nq * k, o); fwrite(cnt.data(), 4, nq, o); }
     } else {
         std::vector<uint64_t> idx(nq * k ? nq * k : 1);
         std::vector<int32_t> sc(nq * k ? nq * k : 1);

@@ -204,6 +204,39 @@ def test_fused_topk_sample_and_lists(oracle, runner, tmp_path):
             assert got == exp, (sk, k, ms, q, got[:5], exp[:5])
 
 
+def test_submit_wait_two_in_flight(oracle, runner, tmp_path):
+    """fz_query_topk_submit / fz_query_topk_wait (runner op 5: two calls in flight, a refused third, waits in reverse
+    order, a ticket fetched twice refused): the matrix path, the fused path, and a fused call whose list overflows
+    (the hits sit outside the sample tiles, so the sample limit stays at the threshold and the row's 2 048 slots do
+    not hold them: the wait redoes that row through the score matrix)"""
+    cps_a, offs_a = synth.make_corpus(420, max_chars=14, seed=81, vocab_size=40, max_tokens=4)
+    cps_b, offs_b = synth.make_corpus(330, max_chars=64, seed=82, vocab_size=40)
+    cand = synth.to_strings(cps_a, offs_a) + synth.to_strings(cps_b, offs_b) + ["x" * 70, "ab " * 30]
+    queries = synth.make_queries(cps_a, offs_a, 4, seed=83) + synth.make_queries(cps_b, offs_b, 3, seed=84) + [cand[0].split()[0], "", "y" * 70]
+    buf, o = oracle.pack(cand)
+    fused = {"FUZZYHIP_SAMPLE_MIN_TILES": "4", "FUZZYHIP_SAMPLE_EVERY": "2", "FUZZYHIP_FUSED_MIN_MB": "0", "FUZZYHIP_TRACE": "1"}
+    for env, k, ms in (({}, 10, 35), (fused, 10, 35), (fused, 64, 0)):
+        idx, score, cnt = _run(runner, tmp_path, 5, 0, cand, queries, min_score=ms, k=k, env=env)
+        assert ("fused top-k over" in _run.last_stderr) == bool(env)
+        for qi, q in enumerate(queries):
+            exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, ms, k)
+            got = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
+            assert got == exp, (k, ms, q, got[:5], exp[:5])
+    # overflow: 80 tiles of one canonical length (physical order = list order); the sample is every 2nd tile (the odd
+    # ones), the 2 560 candidates that hold the query's token sit in the even ones: the sample finds nothing
+    rng = np.random.default_rng(85)
+    fill = ["".join(chr(97 + int(x)) for x in rng.integers(0, 20, 6)) for _ in range(64 * 80)]
+    cand = [("zz " if (i // 64) % 2 == 0 else "yy ") + f for i, f in enumerate(fill)]
+    queries = ["zz", "zz " + fill[7], "qq", "zz"]
+    buf, o = oracle.pack(cand)
+    idx, score, cnt = _run(runner, tmp_path, 5, 0, cand, queries, min_score=100, k=5, env=fused)
+    assert "rows overflowed their lists" in _run.last_stderr, _run.last_stderr[-800:]
+    for qi, q in enumerate(queries):
+        exp = oracle.topk(oracle.TOKEN_SET, q, buf, o, 100, 5)
+        got = [(int(idx[qi, j]), int(score[qi, j])) for j in range(int(cnt[qi]))]
+        assert got == exp, (q, got[:5], exp[:5])
+
+
 def test_query_tables_built_by_threads(oracle, runner, tmp_path):
     """>= 256 queries in one chunk: the host builds the query tables on several threads (stream rows handed
     out first, per-thread batches appended with their offsets moved); token_set over the stream kernels and

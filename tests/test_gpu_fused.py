@@ -166,6 +166,61 @@ def test_fused_list_overflow_falls_back(oracle, monkeypatch):
         assert _rows(*got) == exp
 
 
+def test_submit_wait_two_in_flight(oracle, monkeypatch):
+    """fz_query_topk_submit / fz_query_topk_wait: two batches in flight on one corpus, fetched in either order, give
+    what fz_query_topk gives -- fused path (a 200 000-candidate shard, 600 queries) and matrix path (3 queries);
+    a third submit is refused; a fused call whose list overflows is repaired by its wait while another call is in
+    flight behind it (the corpus of test_fused_list_overflow_falls_back)."""
+    n, k, ms = 200_000, 10, 35
+    cps, offs = synth.make_corpus(n, max_chars=64, seed=531)
+    qa = synth.make_queries(cps, offs, 600, seed=532, max_chars=64)
+    qb = synth.make_queries(cps, offs, 500, seed=533, max_chars=64)
+    with Corpus(cps, offs) as c:
+        ref_a, ref_b, ref_s = c.topk(qa, ms, k), c.topk(qb, ms, k), c.topk(qa[:3], ms, k)
+        assert c.topk(qa, ms, k) and c.timing()["fused"] == 1
+        ta = c.topk_submit(qa, ms, k)
+        tb = c.topk_submit(qb, ms, k)
+        with pytest.raises(_lib.FuzzyHipError):
+            c.topk_submit(qa[:3], ms, k)
+        got_b = c.topk_wait(tb)                                    # the later call first
+        ts = c.topk_submit(qa[:3], ms, k)                          # its slot is free again; matrix path (3 rows)
+        got_a = c.topk_wait(ta)
+        got_s = c.topk_wait(ts)
+        with pytest.raises(RuntimeError):
+            c.topk_wait(ts)
+        for got, ref in ((got_a, ref_a), (got_b, ref_b), (got_s, ref_s)):
+            for a, b in zip(got, ref):
+                assert (a == b).all()
+        # a queue of batches, two in flight throughout
+        prev, outs = None, []
+        for i in range(6):
+            t = c.topk_submit(qa if i % 2 == 0 else qb, ms, k)
+            if prev is not None:
+                outs.append(c.topk_wait(prev))
+            prev = t
+        outs.append(c.topk_wait(prev))
+        for i, got in enumerate(outs):
+            for a, b in zip(got, ref_a if i % 2 == 0 else ref_b):
+                assert (a == b).all(), i
+    _force_fused(monkeypatch)
+    rng = np.random.default_rng(521)
+    n = 64 * 320
+    fill = ["".join(chr(97 + int(x)) for x in rng.integers(0, 20, 6)) for _ in range(n)]
+    cand = ["yy " + f for f in fill]
+    slots = [i for i in range(n) if (i // 64) % 16 != 8 and (i // 64) != n // 64 - 1]
+    for i in rng.choice(len(slots), 3000, replace=False):
+        cand[slots[int(i)]] = "zz " + fill[slots[int(i)]]
+    queries = ["zz", "zz " + fill[slots[5]], "yy", "qq"]
+    buf, o = oracle.pack(cand)
+    exp = _oracle_topk_rows(oracle, oracle.TOKEN_SET, queries, buf, o, 100, 64)
+    with Corpus.from_prepared(cand) as c:
+        t1 = c.topk_submit(queries, 100, 64)                       # 'zz' overflows its list
+        t2 = c.topk_submit(queries[2:], 100, 64)                   # queued behind it; reuses the workspace
+        g1 = _rows(*c.topk_wait(t1))                               # redoes row 0 behind t2's kernels
+        g2 = _rows(*c.topk_wait(t2))
+        assert g1 == exp and g2 == exp[2:]
+
+
 def test_fused_sharded_exchange(monkeypatch):
     """fz_query_topk_sharded with fused local top-k calls: 2 and 3 ranks as threads over the RCCL stand-in on
     shards of >= 256 tiles (tests/comm_case.py 'threads_fused'), results equal to the single-corpus top-k"""

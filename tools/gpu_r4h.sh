@@ -1,0 +1,4 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+echo "-- rocm"; timeout -k 10 120 python tools/pipe_probe.py 20
+echo "-- torch"; FUZZYHIP_HIP_RUNTIME=torch timeout -k 10 120 python tools/pipe_probe.py 20

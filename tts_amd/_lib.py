@@ -60,6 +60,9 @@ _SIGNATURES = {
                                      ctypes.c_int32, ctypes.c_uint32, c_u64p, c_i32p, c_u32p]),
     "fz_query_topk_noalloc": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int,
                                              ctypes.c_int32, ctypes.c_uint32, c_u64p, c_i32p, c_u32p]),
+    "fz_query_topk_submit": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int,
+                                            ctypes.c_int32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]),
+    "fz_query_topk_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_u64p, c_i32p, c_u32p]),
     "fz_query_topk_keys": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, ctypes.c_uint32, ctypes.c_int,
                                           ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int]),

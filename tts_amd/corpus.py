@@ -120,6 +120,29 @@ class Corpus:
                       _u64(idx), score.ctypes.data_as(_lib.c_i32p), _u32(cnt)))
         return idx[:, :k], score[:, :k], cnt[:nq]
 
+    def topk_submit(self, queries, min_score: int, k: int, scorer: int = _lib.TOKEN_SET) -> "TopkTicket":
+        """First half of ``topk`` (``fz_query_topk_submit``): tables built, every kernel enqueued, nothing waited for.
+        At most ``MAX_IN_FLIGHT`` tickets per corpus; fetch each with ``topk_wait``.  The ticket keeps the query arrays
+        alive (the library reads them again if a fused list overflows)."""
+        q_cps, q_offs, nq = self._pack_queries(queries)
+        t = ctypes.c_int(-1)
+        _lib.check(self._lib.fz_query_topk_submit(self._handle(), _u32(q_cps), _u64(q_offs), nq, int(scorer),
+                                                  int(min_score), int(k), ctypes.byref(t)))
+        return TopkTicket(t.value, nq, int(k), q_cps, q_offs)
+
+    def topk_wait(self, ticket: "TopkTicket"):
+        """Second half (``fz_query_topk_wait``): blocks until the call's result is there; same return value as ``topk``."""
+        if ticket.done:
+            raise RuntimeError("ticket already fetched")
+        nq, k = ticket.nq, ticket.k
+        idx = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        score = np.zeros((nq, max(k, 1)), dtype=np.int32)
+        cnt = np.zeros(max(nq, 1), dtype=np.uint32)
+        ticket.done = True
+        _lib.check(self._lib.fz_query_topk_wait(self._handle(), ticket.slot, _u64(idx), score.ctypes.data_as(_lib.c_i32p), _u32(cnt)))
+        ticket.q_cps = ticket.q_offs = None
+        return idx[:, :k], score[:, :k], cnt[:nq]
+
     def topk_sharded(self, comm_handle: int, queries, min_score: int, k: int, scorer: int = _lib.TOKEN_SET):
         """Collective: top-k over the WHOLE sharded list (this corpus is one shard).  The exchange -- RCCL
         all-gather of the packed keys and the device merge -- runs inside the library
@@ -182,6 +205,17 @@ class Corpus:
 
     def set_workspace_limit(self, nbytes: int) -> None:
         _lib.check(self._lib.fz_set_workspace_limit(self._handle(), int(nbytes)))
+
+
+MAX_IN_FLIGHT = 2          # FZ_MAX_IN_FLIGHT (include/fuzzyhip.h)
+
+
+class TopkTicket:
+    """A submitted, not yet fetched ``Corpus.topk_submit`` call."""
+    __slots__ = ("slot", "nq", "k", "q_cps", "q_offs", "done")
+
+    def __init__(self, slot: int, nq: int, k: int, q_cps, q_offs):
+        self.slot, self.nq, self.k, self.q_cps, self.q_offs, self.done = slot, nq, k, q_cps, q_offs, False
 
 
 def list_fingerprint(items: Sequence[str]):

@@ -178,6 +178,8 @@ struct Workspace {
 };
 #define FZ_COUNTER_SLOTS 64u
 
+struct Prepared;
+
 struct fz_corpus {
     int device = 0;
     uint64_t base = 0, n = 0;
@@ -213,6 +215,7 @@ struct fz_corpus {
     uint64_t slab_bytes = 24ull << 20;                    // FUZZYHIP_SLAB_KB: corpus bytes one stream kernel keeps cache resident
     uint32_t stream_oversub = 1;                          // FUZZYHIP_STREAM_OVERSUB: persistent blocks per slot
     uint32_t pipe_chunks = 1;                             // FUZZYHIP_CHUNKS: pieces of a large top-k batch
+    bool submit_eager = false;                            // FUZZYHIP_SUBMIT_EAGER=1: fz_query_topk_submit enqueues behind a running call
     uint32_t stream_waves = 0, stream_blocks = 192;       // tuning knobs (FUZZYHIP_STREAM_WAVES: waves per block, 0 = by kernel; _BLOCKS)
     // sliced select (FzSelectParams::n_slices): a few rows over a large shard are selected by several blocks per row
     uint64_t *d_slice_keys = nullptr; uint32_t *d_slice_done = nullptr;
@@ -237,6 +240,27 @@ struct fz_corpus {
         int view_kind = 0, kmode = 0; FzTies ties{0, 0};
         uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr; int32_t min_score = 0; uint32_t k = 0, flat = 0;
     } async_fused;
+    // query tables built ahead by a fz_query_topk_submit that found the GPU busy (prepare_rows takes them when the call is launched)
+    struct Prebuilt {
+        bool valid = false;
+        const uint32_t *q_cps = nullptr; const uint64_t *q_offs = nullptr; uint64_t q0 = 0; uint32_t rows = 0; int view_kind = 0, kmode = 0;
+        std::shared_ptr<Prepared> P;
+    } prebuilt;
+    // fz_query_topk_submit / fz_query_topk_wait: calls submitted whose result has not been fetched.  `launched` is false
+    // while a call only has its tables built (the GPU was busy with the call before it)
+    struct Flight {
+        bool busy = false, empty = false, fused = false, launched = false;
+        int scorer = 0;
+        uint64_t seq = 0;
+        const uint32_t *q_cps = nullptr; const uint64_t *q_offs = nullptr; uint32_t nq = 0, k = 0, flat = 0;
+        int view_kind = 0, kmode = 0; FzTies ties{0, 0}; int32_t min_score = 0;
+        uint32_t nchunks = 0; uint64_t rows_per_chunk = 0;
+        uint64_t *d_keys = nullptr; size_t d_words = 0;     // nq*k keys + the status word
+        uint64_t *h_keys = nullptr; size_t h_words = 0;     // pinned copy of the same
+        uint32_t *h_ovf = nullptr;                          // pinned [FZ_FUSED_MAX_CHUNKS | 1 + FZ_FUSED_REDO_ROWS]: the call's overflow records
+        hipEvent_t done = nullptr;
+    } flight[FZ_MAX_IN_FLIGHT];
+    uint64_t flight_seq = 0;
     std::mutex mu;
 };
 
@@ -335,6 +359,12 @@ extern "C" void fz_corpus_destroy(fz_corpus *c)
                     (void *)c->d_score_tab[0], (void *)c->d_score_tab[1], (void *)c->d_ranks, (void *)c->d_rank_tab, (void *)w.d_counters,
                     (void *)c->d_slice_keys, (void *)c->d_slice_done})
         if (p) (void)hipFree(p);
+    for (fz_corpus::Flight &f : c->flight) {
+        if (f.d_keys) (void)hipFree(f.d_keys);
+        if (f.h_keys) (void)hipHostFree(f.h_keys);
+        if (f.h_ovf) (void)hipHostFree(f.h_ovf);
+        if (f.done) (void)hipEventDestroy(f.done);
+    }
     for (int i = 0; i < 2; ++i) {
         if (c->h_blob[i]) (void)hipHostFree(c->h_blob[i]);
         if (c->ev_blob[i]) (void)hipEventDestroy(c->ev_blob[i]);
@@ -673,6 +703,7 @@ static int finish_create(fz_corpus *c)
     HIP_TRY(hipMalloc((void **)&c->d_slice_done, 256));
     HIP_TRY(hipMemset(c->d_slice_done, 0, 256));
     if (const char *e = getenv("FUZZYHIP_STREAM_OVERSUB")) c->stream_oversub = (uint32_t)std::min(16, std::max(1, atoi(e)));
+    if (const char *e = getenv("FUZZYHIP_SUBMIT_EAGER")) c->submit_eager = atoi(e) != 0;
     if (const char *e = getenv("FUZZYHIP_CHUNKS")) c->pipe_chunks = (uint32_t)std::min(64, std::max(1, atoi(e)));
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(FZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -1391,12 +1422,13 @@ struct Prepared {
     std::vector<FzQuery> qlist;
     std::vector<Launch> launches;
     size_t o_q = 0, o_peq = 0, o_id = 0, o_pos = 0, o_len = 0, o_rec = 0, o_qrec = 0, o_rows = 0;
+    uint32_t blob = 0; size_t total = 0; double host_ms = 0.0;          // the pinned blob the tables were assembled in
 };
 
 // Builds the query tables of `rows` queries (q0 .. q0+rows; query r of the chunk writes score row r) on
-// the host and uploads them as one blob on `st`.
-static int prepare_rows(fz_corpus *c, int view_kind, int kmode, const uint32_t *q_cps, const uint64_t *q_offs,
-                        uint64_t q0, uint32_t rows, hipStream_t st, Prepared &P)
+// the host, in one of the two pinned blobs (no HIP call but the wait for the blob's last upload).
+static int build_tables(fz_corpus *c, int view_kind, int kmode, const uint32_t *q_cps, const uint64_t *q_offs,
+                        uint64_t q0, uint32_t rows, Prepared &P)
 {
     const View &v = c->views[view_kind];
     int rc;
@@ -1448,8 +1480,10 @@ static int prepare_rows(fz_corpus *c, int view_kind, int kmode, const uint32_t *
     // event), so the host builds the tables of the next chunk while the GPU works on this one.
     Workspace &w = *c->ws;
     const uint32_t bi = c->blob_next++ & 1u;
+    if (c->prebuilt.valid && c->prebuilt.P->blob == bi) c->prebuilt.valid = false;     // tables built ahead lived in this blob
     HIP_TRY(hipEventSynchronize(c->ev_blob[bi]));
     if ((rc = ensure_pinned(w, &c->h_blob[bi], &c->h_blob_cap[bi], total, "query tables")) != FZ_OK) return rc;
+    P.blob = bi; P.total = total;
     uint8_t *blob = c->h_blob[bi];
     if (!P.qlist.empty()) memcpy(blob + P.o_q, P.qlist.data(), P.qlist.size() * sizeof(FzQuery));
     if (!b.peq.empty()) memcpy(blob + P.o_peq, b.peq.data(), b.peq.size() * 4);
@@ -1461,13 +1495,28 @@ static int prepare_rows(fz_corpus *c, int view_kind, int kmode, const uint32_t *
     memcpy(blob + P.o_rec, b.recs.data(), b.recs.size() * sizeof(FzRec));
     if (!b.qrec.empty()) memcpy(blob + P.o_qrec, b.qrec.data(), b.qrec.size() * 4);
     memcpy(blob + P.o_rows, b.row_of_sym, 256);
-    c->timing.host_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if ((rc = ensure(w, &w.d_qbuf, &w.qbuf_cap, total, "query tables")) != FZ_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(w.d_qbuf, blob, total, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(c->ev_blob[bi], st));
+    P.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("FUZZYHIP_PREP_DEBUG"))
         fprintf(stderr, "[prep dbg] %u queries: tables %.3f ms, tables + blob %.3f ms (%zu bytes)\n", rows,
-                std::chrono::duration<double, std::milli>(t_prep - t0).count(), c->timing.host_prep_ms, total);
+                std::chrono::duration<double, std::milli>(t_prep - t0).count(), P.host_ms, total);
+    return FZ_OK;
+}
+
+// prepare = tables (built now, or built ahead by a submit that found the GPU busy: c->prebuilt) + upload on `st`
+static int prepare_rows(fz_corpus *c, int view_kind, int kmode, const uint32_t *q_cps, const uint64_t *q_offs,
+                        uint64_t q0, uint32_t rows, hipStream_t st, Prepared &P)
+{
+    int rc;
+    fz_corpus::Prebuilt &pb = c->prebuilt;
+    if (pb.valid && pb.q_cps == q_cps && pb.q_offs == q_offs && pb.q0 == q0 && pb.rows == rows && pb.view_kind == view_kind && pb.kmode == kmode) {
+        P = std::move(*pb.P);
+        pb.valid = false;
+    } else if ((rc = build_tables(c, view_kind, kmode, q_cps, q_offs, q0, rows, P)) != FZ_OK) return rc;
+    c->timing.host_prep_ms += P.host_ms;
+    Workspace &w = *c->ws;
+    if ((rc = ensure(w, &w.d_qbuf, &w.qbuf_cap, P.total, "query tables")) != FZ_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(w.d_qbuf, c->h_blob[P.blob], P.total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(c->ev_blob[P.blob], st));
     return FZ_OK;
 }
 
@@ -1730,18 +1779,26 @@ static int run_matrix(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_off
 // Lists that overflowed (more than FZ_EMIT_CAP candidates reached the sample's limit: hits clustered in index or length
 // where the sample tiles happen not to fall).  Up to FZ_FUSED_REDO_ROWS such rows are redone one by one through the
 // score matrix -- a row writes its own keys, the others stay --, more than that chunk by chunk.  Results are the
-// same either way.  The stream has been synchronised by the caller.
+// same either way.  The records are host copies taken after the call's kernels (read_overflow, or a submit's pinned copy).
+static int read_overflow(const uint32_t *d_ovf, const uint32_t *d_ovf_rows, uint32_t nchunks, std::vector<uint32_t> &h_ovf, std::vector<uint32_t> &h_rows)
+{
+    h_ovf.assign(FZ_FUSED_MAX_CHUNKS, 0u); h_rows.assign(1u + FZ_FUSED_REDO_ROWS, 0u);
+    HIP_TRY(hipMemcpy(h_ovf.data(), d_ovf, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
+    bool any = false;
+    for (uint32_t i = 0; i < nchunks; ++i) any |= h_ovf[i] != 0u;
+    if (any) HIP_TRY(hipMemcpy(h_rows.data(), d_ovf_rows, h_rows.size() * 4, hipMemcpyDeviceToHost));
+    return FZ_OK;
+}
+
 static int redo_overflow(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq, int view_kind, int kmode,
                          FzTies ties, const TopkTarget &t, RunMode mode, RunOut &o, CallEvents &ev, hipStream_t st,
-                         const uint32_t *d_ovf, const uint32_t *d_ovf_rows, uint32_t nchunks, uint64_t rows_per_chunk)
+                         const uint32_t *h_ovf_p, const uint32_t *h_rows_p, uint32_t nchunks, uint64_t rows_per_chunk)
 {
     int rc;
-    std::vector<uint32_t> h_ovf(nchunks, 0u), h_rows(1u + FZ_FUSED_REDO_ROWS, 0u);
-    HIP_TRY(hipMemcpy(h_ovf.data(), d_ovf, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> h_ovf(h_ovf_p, h_ovf_p + nchunks), h_rows(h_rows_p, h_rows_p + 1u + FZ_FUSED_REDO_ROWS);
     bool any = false;
     for (uint32_t x : h_ovf) any |= x != 0u;
     if (!any) return FZ_OK;
-    HIP_TRY(hipMemcpy(h_rows.data(), d_ovf_rows, h_rows.size() * 4, hipMemcpyDeviceToHost));
     for (uint32_t x : h_ovf) c->timing.fused_fallback_chunks += x != 0u ? 1u : 0u;
     if (h_rows[0] <= FZ_FUSED_REDO_ROWS) {
         std::sort(h_rows.begin() + 1, h_rows.begin() + 1 + h_rows[0]);
@@ -1850,7 +1907,9 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
         return FZ_OK;
     }
     HIP_TRY(hipStreamSynchronize(st));
-    return redo_overflow(c, q_cps, q_offs, nq, view_kind, kmode, ties, t, mode, o, ev, st, d_ovf, d_ovf_rows, nchunks, rows_per_chunk);
+    std::vector<uint32_t> h_ovf, h_rows;
+    if ((rc = read_overflow(d_ovf, d_ovf_rows, nchunks, h_ovf, h_rows)) != FZ_OK) return rc;
+    return redo_overflow(c, q_cps, q_offs, nq, view_kind, kmode, ties, t, mode, o, ev, st, h_ovf.data(), h_rows.data(), nchunks, rows_per_chunk);
 }
 
 // c->mu held by the caller
@@ -1962,8 +2021,11 @@ static int redo_async_overflow(fz_corpus *c, const uint32_t *q_cps, const uint64
     CallEvents ev{c, false};
     RunOut o; o.d_keys = a.d_keys; o.d_cnt = a.d_cnt; o.sync = 1; o.flat = a.flat;
     const TopkTarget t{a.d_keys, a.d_cnt, a.min_score, a.k, a.flat};
-    int rc = redo_overflow(c, q_cps, q_offs, nq, a.view_kind, a.kmode, a.ties, t, RUN_TOPK_DEVICE, o, ev, c->stream,
-                           a.d_ovf, a.d_ovf_rows, a.nchunks, a.rows_per_chunk);
+    std::vector<uint32_t> h_ovf, h_rows;
+    int rc = read_overflow(a.d_ovf, a.d_ovf_rows, a.nchunks, h_ovf, h_rows);
+    if (rc != FZ_OK) return rc;
+    rc = redo_overflow(c, q_cps, q_offs, nq, a.view_kind, a.kmode, a.ties, t, RUN_TOPK_DEVICE, o, ev, c->stream,
+                       h_ovf.data(), h_rows.data(), a.nchunks, a.rows_per_chunk);
     if (rc != FZ_OK) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto &s : ev.score) { float ms = 0; if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) c->timing.score_ms += ms; }
@@ -1991,6 +2053,145 @@ static int fz_query_topk_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_
     RunOut o; o.idx = out_idx; o.score = out_score; o.cnt = out_cnt;
     o.flat = (scorer & FZ_ORDER_BY_INDEX) ? 1u : 0u;
     return run_queries(c, q_cps, q_offs, nq, view, kmode, ties, min_score, k, RUN_TOPK_HOST, o);
+}
+
+// ---- fz_query_topk in two phases -------------------------------------------------------------------------------
+// submit: query tables, upload, every kernel, the copy of keys + status word + overflow records to pinned memory and
+// an event, all enqueued on the corpus' stream; nothing waits for the GPU.  wait: the event, then (rarely) the rows whose
+// fused lists overflowed redone through the score matrix, then the keys decoded.  One stream carries every call of
+// a corpus, so the workspace a later call reuses is only touched after the earlier call's copies have run; what a
+// call must keep until its wait lives in its slot (c->flight).  The host work of call i+1 -- 0.13 ms of table
+// building per 1000 queries, the Python side, the decoding of call i-1 -- then passes under the kernels of call i.
+// enqueue everything of a submitted call: upload, kernels, the copy of keys + status (+ overflow records), the event
+static int launch_flight(fz_corpus *c, fz_corpus::Flight &f)
+{
+    int rc;
+    const size_t nkeys = (size_t)f.nq * f.k, words = nkeys + 1;
+    hipStream_t st = c->stream;
+    f.fused = false;
+    if (!f.empty) {
+        RunOut o; o.d_keys = f.d_keys; o.d_cnt = nullptr; o.sync = 0; o.d_status = f.d_keys + nkeys; o.flat = f.flat;
+        HIP_TRY(hipMemsetAsync(f.d_keys + nkeys, 0, 8, st));          // (a call that takes the matrix path never writes it)
+        if ((rc = run_queries_locked(c, f.q_cps, f.q_offs, f.nq, f.view_kind, f.kmode, f.ties, f.min_score, f.k, RUN_TOPK_DEVICE, o)) != FZ_OK) return rc;
+        st = c->stream;
+        fz_corpus::AsyncFused &a = c->async_fused;
+        if (a.valid) {                                               // the overflow records leave the workspace with the call
+            f.fused = true; f.nchunks = a.nchunks; f.rows_per_chunk = a.rows_per_chunk;
+            HIP_TRY(hipMemcpyAsync(f.h_ovf, a.d_ovf, (size_t)a.nchunks * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(f.h_ovf + FZ_FUSED_MAX_CHUNKS, a.d_ovf_rows, (size_t)(1u + FZ_FUSED_REDO_ROWS) * 4, hipMemcpyDeviceToHost, st));
+            a.valid = false;
+        }
+        HIP_TRY(hipMemcpyAsync(f.h_keys, f.d_keys, words * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(f.done, st));
+    f.seq = ++c->flight_seq;
+    f.launched = true;
+    return FZ_OK;
+}
+
+static int fz_query_topk_submit_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                                     int scorer, int32_t min_score, uint32_t k, int *ticket)
+{
+    if (!c || !ticket) return fail(FZ_ERR_INVALID, "null corpus or ticket");
+    *ticket = -1;
+    int view, kmode; FzTies ties; int rc;
+    if ((rc = scorer_plan(scorer & 0xFF, &view, &kmode, &ties)) != FZ_OK) return rc;
+    if (k > FZ_MAX_K) return fail(FZ_ERR_LIMIT, "k=%u exceeds FZ_MAX_K=%u", k, FZ_MAX_K);
+    if (nq && (!q_offs || (!q_cps && q_offs[nq] != q_offs[0]))) return fail(FZ_ERR_INVALID, "null query buffers");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int si = -1;
+    bool gpu_busy = false;                                           // a call of this corpus launched and not fetched yet
+    for (int i = 0; i < (int)FZ_MAX_IN_FLIGHT; ++i) {
+        if (!c->flight[i].busy) { if (si < 0) si = i; }
+        else gpu_busy |= c->flight[i].launched;
+    }
+    if (si < 0) return fail(FZ_ERR_LIMIT, "fz_query_topk_submit: %u calls of this corpus are in flight already; fetch one with fz_query_topk_wait first", FZ_MAX_IN_FLIGHT);
+    fz_corpus::Flight &f = c->flight[si];
+    if (!f.done) HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    if (!f.h_ovf) HIP_TRY(hipHostMalloc((void **)&f.h_ovf, (size_t)(FZ_FUSED_MAX_CHUNKS + 1u + FZ_FUSED_REDO_ROWS) * 4, hipHostMallocDefault));
+    const size_t nkeys = (size_t)nq * k, words = nkeys + 1;
+    if (f.d_words < words) {
+        if (f.d_keys) { HIP_TRY(hipFree(f.d_keys)); f.d_keys = nullptr; f.d_words = 0; }
+        HIP_TRY(hipMalloc((void **)&f.d_keys, words * 8));
+        f.d_words = words;
+    }
+    if (f.h_words < words) {
+        if (f.h_keys) { HIP_TRY(hipHostFree(f.h_keys)); f.h_keys = nullptr; f.h_words = 0; }
+        HIP_TRY(hipHostMalloc((void **)&f.h_keys, words * 8, hipHostMallocDefault));
+        f.h_words = words;
+    }
+    f.q_cps = q_cps; f.q_offs = q_offs; f.nq = nq; f.k = k; f.flat = (scorer & FZ_ORDER_BY_INDEX) ? 1u : 0u;
+    f.view_kind = view; f.kmode = kmode; f.ties = ties; f.min_score = min_score;
+    f.fused = false; f.launched = false; f.empty = nkeys == 0;
+    if (gpu_busy && !c->submit_eager) {
+        // The GPU works on the call before this one: only the host part happens now -- the query tables, built into a
+        // pinned blob --, and the call is enqueued by the fz_query_topk_wait that sees its predecessor finish (the
+        // first thing that wait does).  Enqueueing behind running kernels instead lets the GPU go from one call to
+        // the next without the host, but the HIP runtime PyTorch wheels bundle (7.0) then stalls inside the launches
+        // (3.15 ms per C2 step against 2.65 with ROCm 7.2's, 2.80 one call at a time): FUZZYHIP_SUBMIT_EAGER=1.
+        if (!f.empty && c->views[view].built && c->n != 0 && min_score <= 100) {
+            fz_corpus::Prebuilt &pb = c->prebuilt;
+            pb.valid = false;
+            pb.P = std::make_shared<Prepared>();
+            if ((rc = build_tables(c, view, kmode, q_cps, q_offs, 0, nq, *pb.P)) != FZ_OK) return rc;
+            pb.q_cps = q_cps; pb.q_offs = q_offs; pb.q0 = 0; pb.rows = nq; pb.view_kind = view; pb.kmode = kmode;
+            pb.valid = true;
+        }
+    } else if ((rc = launch_flight(c, f)) != FZ_OK) return rc;
+    f.busy = true;
+    *ticket = si;
+    return FZ_OK;
+}
+
+static int fz_query_topk_wait_impl(fz_corpus *c, int ticket, uint64_t *out_idx, int32_t *out_score, uint32_t *out_cnt)
+{
+    if (!c) return fail(FZ_ERR_INVALID, "null corpus");
+    if (ticket < 0 || ticket >= (int)FZ_MAX_IN_FLIGHT) return fail(FZ_ERR_INVALID, "fz_query_topk_wait: no such ticket (%d)", ticket);
+    fz_corpus::Flight &f = c->flight[ticket];
+    struct Release { fz_corpus::Flight &f; bool armed = false; ~Release() { if (armed) f.busy = false; } } release{f};     // on every way out
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!f.busy) return fail(FZ_ERR_INVALID, "fz_query_topk_wait: ticket %d is not in flight", ticket);
+        if (f.nq && f.k && (!out_idx || !out_score)) return fail(FZ_ERR_INVALID, "null output buffers");
+        release.armed = true;
+        if (!f.launched) {                                           // fetched before its predecessor: it goes behind it now
+            HIP_TRY(hipSetDevice(c->device));
+            int rc = launch_flight(c, f);
+            if (rc != FZ_OK) return rc;
+        }
+    }
+    // the slot does not change while it is busy: the wait for the GPU runs outside the lock, so that another thread can
+    // submit meanwhile
+    hipError_t he = hipEventSynchronize(f.done);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (he != hipSuccess) return fail(FZ_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(he));
+    HIP_TRY(hipSetDevice(c->device));
+    // the GPU is free: the call that was waiting with its tables built goes out before this one's result is decoded
+    int deferred_rc = FZ_OK; std::string deferred_err;
+    for (fz_corpus::Flight &g : c->flight)
+        if (&g != &f && g.busy && !g.launched && (deferred_rc = launch_flight(c, g)) != FZ_OK) { deferred_err = g_err; g.busy = false; }
+    if (f.empty) {
+        if (out_cnt && f.nq) memset(out_cnt, 0, (size_t)f.nq * 4);
+    } else {
+        const size_t nkeys = (size_t)f.nq * f.k;
+        if (f.seq == c->flight_seq) finish_pending_timing(c);         // the kernel times of the last call launched
+        if (f.fused && f.h_keys[nkeys] != 0ull) {
+            // rows whose lists overflowed: redone now, behind whatever was launched since (stream order), into the slot's keys
+            CallEvents ev{c, false};
+            ev.next = 48;                                             // clear of the events a call in flight still needs
+            RunOut o; o.d_keys = f.d_keys; o.d_cnt = nullptr; o.sync = 1; o.flat = f.flat;
+            const TopkTarget t{f.d_keys, nullptr, f.min_score, f.k, f.flat};
+            int rc = redo_overflow(c, f.q_cps, f.q_offs, f.nq, f.view_kind, f.kmode, f.ties, t, RUN_TOPK_DEVICE, o, ev, c->stream,
+                                   f.h_ovf, f.h_ovf + FZ_FUSED_MAX_CHUNKS, f.nchunks, f.rows_per_chunk);
+            if (rc != FZ_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(f.h_keys, f.d_keys, nkeys * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        decode_keys(f.h_keys, f.nq, f.k, out_idx, out_score, out_cnt);
+    }
+    if (deferred_rc != FZ_OK) return fail(deferred_rc, "the call submitted after this one could not be launched (its ticket is void): %s", deferred_err.c_str());
+    return FZ_OK;
 }
 
 // fz_query_topk over the static scratch array: nothing is allocated (see include/fuzzyhip.h).
@@ -2472,6 +2673,17 @@ extern "C" int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t
                              int32_t *out_score, uint32_t *out_cnt)
 {
     return guarded([&] { return fz_query_topk_impl(c, q_cps, q_offs, nq, scorer, min_score, k, out_idx, out_score, out_cnt); });
+}
+
+extern "C" int fz_query_topk_submit(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
+                                    int scorer, int32_t min_score, uint32_t k, int *ticket)
+{
+    return guarded([&] { return fz_query_topk_submit_impl(c, q_cps, q_offs, nq, scorer, min_score, k, ticket); });
+}
+
+extern "C" int fz_query_topk_wait(fz_corpus *c, int ticket, uint64_t *out_idx, int32_t *out_score, uint32_t *out_cnt)
+{
+    return guarded([&] { return fz_query_topk_wait_impl(c, ticket, out_idx, out_score, out_cnt); });
 }
 
 extern "C" int fz_query_topk_noalloc(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,

@@ -147,6 +147,12 @@ __device__ __forceinline__ void fz_clear_bits(uint32_t *row, uint32_t s, uint32_
 // WIDE: the corpus has more than 254 distinct code points, so its symbols are 16 bits (two per
 //       dword) and the Peq table is indirect: a u16 map [alphabet] -> row of a table that only holds
 //       the symbols of THIS query (row 0 = all zero = every other symbol), both in LDS.
+// LDS row stride (words) of a Peq table of W-word rows.  Every lane reads the row of ITS text symbol, so the 64 lanes
+// of a word read land on rows chosen by the data: with an even stride rows share banks (W = 8: eight start banks for
+// ~30 rows; 75 % of the kernel's cycles were LDS bank-conflict cycles, SQ_LDS_BANK_CONFLICT), with an odd stride up to
+// 64 distinct rows fall on 64 distinct banks and a word read is conflict-free.
+__host__ __device__ constexpr uint32_t fz_peq_stride(int W) { return (uint32_t)W | 1u; }
+
 template <bool WIDE>
 struct FzSym {
     static constexpr int SPD = WIDE ? 2 : 4;                  // symbols per dword
@@ -160,8 +166,9 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 {
     using SY = FzSym<WIDE>;
     extern __shared__ __align__(16) uint32_t lds[];
-    uint32_t *s_peq = lds;                                    // [peq_rows][W]
-    uint32_t *s_qid = s_peq + p.peq_rows * W;                 // [pmax] query token ids, ascending
+    constexpr uint32_t RS = fz_peq_stride(W);
+    uint32_t *s_peq = lds;                                    // [peq_rows][RS]: rows of W words at an odd stride
+    uint32_t *s_qid = s_peq + p.peq_rows * RS;                // [pmax] query token ids, ascending
     uint32_t *s_qpos = s_qid + p.pmax;                        // first pattern bit of the token
     uint32_t *s_qlen = s_qpos + p.pmax;                       // token length + 1
     uint32_t *s_M = s_qlen + p.pmax;                          // [nwaves][W][64] pattern keep masks
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
     const FzQuery q = p.queries[blockIdx.y];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-    for (uint32_t i = tid; i < q.peq_rows * (uint32_t)W; i += blockDim.x) s_peq[i] = p.qblob[q.peq_off + i];
+    for (uint32_t i = tid; i < q.peq_rows * (uint32_t)W; i += blockDim.x) s_peq[(i / (uint32_t)W) * RS + i % (uint32_t)W] = p.qblob[q.peq_off + i];
     if (WIDE) {
         uint32_t *m32 = s_TK + p.nwaves * p.ntkw * 64u;
         for (uint32_t i = tid; i < (p.alphabet + 1u) / 2u; i += blockDim.x) m32[i] = p.qblob[q.map_off + i];
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 #pragma unroll
                 for (int k = 0; k < SY::SPD; ++k) {
                     const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;   // padding symbols clear D: no false hit
-                    const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
+                    const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * RS;
                     uint32_t carry = 1u;
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
                 for (int k = 0; k < SY::SPD; ++k) {
                     if (d * (uint32_t)SY::SPD + (uint32_t)k < clen && q.m != 0u) {     // padding is not text here
                         const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
-                        const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
+                        const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * RS;
                         uint64_t carry = 0ull;
                         uint32_t phc = 1u, mhc = 0u;
 #pragma unroll
@@ -303,15 +310,18 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
         for (int w = 0; w < W; ++w) { M[w] = Mrow[w * 64]; V[w] = 0xFFFFFFFFu; }
 
         // ---- bit-parallel LCS over the kept text --------------------------------------------
-        uint32_t tkw = 0u;
+        // the next symbol dword is asked for before this one is scanned: its latency (the corpus of long strings comes
+        // from HBM) passes under ~100 instructions of carry chain instead of being waited for at the top of every turn
+        uint32_t tkw = 0u, cw_next = td.ndw ? symp[0] : 0u;
         for (uint32_t d = 0; d < td.ndw; ++d) {
-            const uint32_t cw = symp[d * 64u];
+            const uint32_t cw = cw_next;
+            if (d + 1u < td.ndw) cw_next = symp[(d + 1u) * 64u];
             if ((d % SY::TKD) == 0u) tkw = TKrow[(d / SY::TKD) * 64u];
 #pragma unroll
             for (int k = 0; k < SY::SPD; ++k) {
                 uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
                 if (((tkw >> k) & 1u) == 0u) s = FZ_SYM_NULL;  // removed token: no match, no change
-                const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
+                const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * RS;
                 uint64_t carry = 0ull;
                 V[0] = fz_lcs_word<true>(V[0], row[0], M[0], carry);
 #pragma unroll
@@ -368,13 +378,14 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
 {
     using SY = FzSym<WIDE>;
     extern __shared__ __align__(16) uint32_t lds[];
-    uint32_t *s_peq = lds;                                    // [peq_rows][W]
+    constexpr uint32_t RS = fz_peq_stride(W);
+    uint32_t *s_peq = lds;                                    // [peq_rows][RS]
     // same LDS layout as fz_score_general (fz_score_lds_bytes): the map sits behind the mask arrays
-    uint32_t *m32 = s_peq + p.peq_rows * W + 3u * p.pmax + p.nwaves * 64u * ((uint32_t)W + p.ntkw);
+    uint32_t *m32 = s_peq + p.peq_rows * RS + 3u * p.pmax + p.nwaves * 64u * ((uint32_t)W + p.ntkw);
     const uint16_t *s_map = reinterpret_cast<const uint16_t *>(m32);
     const FzQuery q = p.queries[blockIdx.y];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t i = tid; i < q.peq_rows * (uint32_t)W; i += blockDim.x) s_peq[i] = p.qblob[q.peq_off + i];
+    for (uint32_t i = tid; i < q.peq_rows * (uint32_t)W; i += blockDim.x) s_peq[(i / (uint32_t)W) * RS + i % (uint32_t)W] = p.qblob[q.peq_off + i];
     if (WIDE)
         for (uint32_t i = tid; i < (p.alphabet + 1u) / 2u; i += blockDim.x) m32[i] = p.qblob[q.map_off + i];
     __syncthreads();
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
                 for (uint32_t j = i; j < jend; ++j) {
                     if (j == i || (j % (uint32_t)SY::SPD) == 0u) cw = symp[(j / (uint32_t)SY::SPD) * 64u];
                     const uint32_t s = (cw >> ((uint32_t)SY::BITS * (j % (uint32_t)SY::SPD))) & SY::MASK;
-                    const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
+                    const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * RS;
                     uint64_t carry = 0ull;
                     V[0] = fz_lcs_word<true>(V[0], row[0], 0xFFFFFFFFu, carry);
 #pragma unroll
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(256) void fz_score_partial(FzScoreParams p)
 #pragma unroll
                     for (int k = 0; k < SY::SPD; ++k) {
                         const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
-                        const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * (uint32_t)W;
+                        const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * RS;
                         uint64_t carry = 0ull;
 #pragma unroll
                         for (int w = 0; w < W; ++w) {
@@ -2109,7 +2120,7 @@ int fz_pick_width(uint32_t m)
 
 size_t fz_score_lds_bytes(int W, const FzScoreParams &p)
 {
-    return 4ull * ((size_t)p.peq_rows * W + 3ull * p.pmax + (size_t)p.nwaves * 64ull * ((size_t)W + p.ntkw) +
+    return 4ull * ((size_t)p.peq_rows * fz_peq_stride(W) + 3ull * p.pmax + (size_t)p.nwaves * 64ull * ((size_t)W + p.ntkw) +
                    (p.wide ? ((size_t)p.alphabet + 1ull) / 2ull : 0ull));
 }
 
