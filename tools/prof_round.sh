@@ -12,6 +12,7 @@ NS=${PROF_STEPS_TIMED:-3}
 timeout -k 10 600 python bench.py $BENCH_ARGS > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 B="python3 bench.py $BENCH_ARGS --steps $NS --warmup 1 --no-cpu-baseline --latency-reps 0"
 export PROF_STEPS=$((NS+1)) PROF_CMD="$B"
+export FUZZYHIP_BENCH_NO_PIPELINE=1      # the profiled runs make warm-up + NS synchronous steps and nothing else (the counters are divided by that)
 timeout -s KILL ${PROF_TIMEOUT:-120} rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -o ${TAG} -- $B > $O/${TAG}_trace.log 2>&1
 timeout -s KILL ${PROF_TIMEOUT:-120} rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o p -- $B > $O/${TAG}_pmc_fetch.log 2>&1
 timeout -s KILL ${PROF_TIMEOUT:-120} rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o p -- $B > $O/${TAG}_pmc_write.log 2>&1

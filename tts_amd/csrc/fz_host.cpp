@@ -177,6 +177,7 @@ struct Workspace {
     bool fixed = false;                                   // true: carved from the static scratch, a larger need is an error
 };
 #define FZ_COUNTER_SLOTS 64u
+#define FZ_COUNTERS_AHEAD 8u      // slots zeroed by the one fill at a call's first stream launch (a fused call of one chunk uses six)
 
 struct Prepared;
 
@@ -198,7 +199,8 @@ struct fz_corpus {
     Workspace own_ws;                                     // grown on demand by the ordinary entry points
     Workspace *ws = &own_ws;                              // fz_query_topk_noalloc points it at the static scratch for one call
     uint8_t *d_score_tab[2] = {nullptr, nullptr};         // stream kernel: T[L][d] per rounding form
-    uint32_t counter_next = 0;
+    uint32_t counter_next = 0, counters_clean = 0;        // work-queue counter slots of the current call: next to hand out, zeroed ahead
+    uint64_t call_seq = 0, counters_call = ~0ull;          // calls run so far; the call the counters were last zeroed for
     // pinned host staging: the query blob of a chunk (two buffers, so the host fills one while the copy
     // engine still reads the other) and the keys read back at the end of a call
     uint8_t *h_blob[2] = {nullptr, nullptr}; size_t h_blob_cap[2] = {0, 0};
@@ -1590,6 +1592,13 @@ static int launch_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, cons
         // upload and joined before anything reads the scores, so that one kernel's blocks start on the CUs
         // another one's tail frees.
         const bool side_by_side = c->overlap && ((counts[0] != 0) + (counts[1] != 0) + (counts[2] != 0)) > 1;
+        // the work-queue counters of a call's first FZ_COUNTERS_AHEAD launches are zeroed by ONE fill on the caller's
+        // stream, in front of the fork (a fill per launch cost six small kernels per fused call, four of them on the
+        // side streams behind the first kernel's persistent blocks); every kernel of earlier calls has finished by then
+        if (c->counters_call != c->call_seq) {
+            HIP_TRY(hipMemsetAsync(w.d_counters, 0, (size_t)FZ_COUNTERS_AHEAD * FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), st));
+            c->counters_call = c->call_seq; c->counter_next = 0; c->counters_clean = FZ_COUNTERS_AHEAD;
+        }
         if (side_by_side) {
             HIP_TRY(hipEventRecord(c->ev_fork, st));
             for (hipStream_t a : c->aux_stream) HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
@@ -1633,8 +1642,9 @@ static int launch_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, cons
             // small items (few queries per group) are drawn several at a time, but never so many that
             // the chip's blocks cannot all get a share
             p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1u, 32u / p.q_per_block), p.nitems / p.grid_blocks));
-            p.work_counter = w.d_counters + (size_t)(c->counter_next++ % FZ_COUNTER_SLOTS) * FZ_STREAM_QUEUES * FZ_STREAM_QPAD;
-            HIP_TRY(hipMemsetAsync(p.work_counter, 0, FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), lst));
+            const uint32_t slot = c->counter_next++;
+            p.work_counter = w.d_counters + (size_t)(slot % FZ_COUNTER_SLOTS) * FZ_STREAM_QUEUES * FZ_STREAM_QPAD;
+            if (slot >= c->counters_clean) HIP_TRY(hipMemsetAsync(p.work_counter, 0, FZ_STREAM_QUEUES * FZ_STREAM_QPAD * sizeof(uint32_t), lst));
             p.row_of_sym = w.d_qbuf + P.o_rows;
             p.recs = reinterpret_cast<const FzRec *>(w.d_qbuf + P.o_rec);
             p.qrec = reinterpret_cast<const uint32_t *>(w.d_qbuf + P.o_qrec);
@@ -1849,7 +1859,7 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
     if (c->pipe_chunks > 1 && nq >= 256u * c->pipe_chunks)
         rows_per_chunk = std::min<uint64_t>(rows_per_chunk, (nq + c->pipe_chunks - 1) / c->pipe_chunks);
     rows_per_chunk = std::max<uint64_t>(rows_per_chunk, (nq + FZ_FUSED_MAX_CHUNKS - 1) / FZ_FUSED_MAX_CHUNKS);
-    const uint64_t o_lim = ovf_bytes, o_cnt = o_lim + a256(rows_per_chunk * 8), o_list = o_cnt + a256(rows_per_chunk * 4);
+    const uint64_t o_cnt = ovf_bytes, o_lim = o_cnt + a256(rows_per_chunk * 4), o_list = o_lim + a256(rows_per_chunk * 8);
     const uint64_t o_sc = o_list + a256(rows_per_chunk * cap * 8);
     const uint64_t arena = o_sc + a256(rows_per_chunk * ns_pad);
     if ((rc = ensure(w, &w.d_scores, &w.scores_cap, (size_t)arena, "fused top-k workspace")) != FZ_OK) return rc;
@@ -1860,8 +1870,8 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
     uint64_t *d_list = reinterpret_cast<uint64_t *>(w.d_scores + o_list);
     uint8_t *d_sc = w.d_scores + o_sc;
     const uint32_t nchunks = (uint32_t)((nq + rows_per_chunk - 1) / rows_per_chunk);
-    HIP_TRY(hipMemsetAsync(d_ovf, 0, (size_t)nchunks * 4, st));
-    HIP_TRY(hipMemsetAsync(d_ovf_rows, 0, 4, st));
+    // one fill: the overflow records and, right behind them, the first chunk's list counts
+    HIP_TRY(hipMemsetAsync(d_ovf, 0, (size_t)(ovf_bytes + std::min<uint64_t>(rows_per_chunk, nq) * 4), st));
 
     uint32_t ci = 0;
     for (uint64_t q0 = 0; q0 < nq; q0 += rows_per_chunk, ++ci) {
@@ -1878,7 +1888,7 @@ static int run_fused(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs
         sp.min_score = t.min_score; sp.k = t.k; sp.base_index = c->base;
         sp.out_keys = t.d_keys + q0 * t.k; sp.out_cnt = nullptr; sp.flat = 0; sp.out_lim = d_lim; sp.walk = v.d_sample_walk;
         HIP_TRY(fz_launch_select(sp, rows, st));
-        HIP_TRY(hipMemsetAsync(d_ecnt, 0, (size_t)rows * 4, st));
+        if (ci != 0) HIP_TRY(hipMemsetAsync(d_ecnt, 0, (size_t)rows * 4, st));
         if ((rc = ev.mark(&e2, st)) != FZ_OK) return rc;
         FzEmit em{};
         em.lim = d_lim; em.list = d_list; em.cnt = d_ecnt; em.cap = cap;
@@ -1938,6 +1948,7 @@ static int run_queries_locked(fz_corpus *c, const uint32_t *q_cps, const uint64_
     c->timing = fz_timing{};
     c->pending.valid = false;
     c->async_fused.valid = false;
+    ++c->call_seq;
 
     const bool nothing = topk && (k == 0 || c->n == 0 || min_score > 100);
     uint64_t *d_keys = nullptr; uint32_t *d_cnt = nullptr;
