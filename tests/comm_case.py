@@ -6,7 +6,10 @@ librccl per process): the sharded entry point fz_query_topk_sharded against the 
     python tests/comm_case.py real      one rank, the real librccl (communicator of size 1)
     python tests/comm_case.py threads_fused   as `threads`, on shards of >= 256 tiles with FUZZYHIP_FUSED_MIN_MB=0
                                         in the environment: every local top-k takes the fused path (asserted);
-                                        expected results come from a score-matrix corpus (FUZZYHIP_NO_FUSED=1)"""
+                                        expected results come from a score-matrix corpus (FUZZYHIP_NO_FUSED=1)
+    python tests/comm_case.py threads_fail    two ranks; the local step of rank 1 fails (it is handed a query beyond
+                                        FZ_MAX_PATTERN): rank 1 raises its own error, rank 0 is told that a peer failed,
+                                        nobody waits in the collective, and the communicator serves the next call"""
 import os
 import sys
 import threading
@@ -112,6 +115,51 @@ def main():
         exp = expected(names, queries, cases)
         del os.environ["FUZZYHIP_NO_FUSED"]
         run_threads(2, names, queries, cases, exp, want_fused=True, want_overflow={cases[0]})
+        print("comm case ok:", mode)
+        return
+    if mode == "threads_fail":
+        assert "fake_rccl" in os.environ.get("FUZZYHIP_RCCL_LIB", "")
+        names, queries = corpus_and_queries()
+        exp = expected(names, queries, cases[:1])
+        box, ready, errors, outcome = {}, threading.Event(), [], {}
+
+        def share(my_id):
+            if my_id is not None:
+                box["id"] = my_id
+                ready.set()
+                return my_id
+            assert ready.wait(60)
+            return box["id"]
+
+        def rank_main(rank):
+            try:
+                lo, hi = shard_bounds(len(names), 2, rank)
+                with Corpus.from_prepared(names[lo:hi], device=0, base_index=lo) as shard:
+                    comm = LibraryExchange(rank, 2, 0, share)
+                    bad = list(queries)
+                    if rank == 1:
+                        bad[3] = " ".join("t%03d" % i for i in range(300))   # 1 500 code points of distinct tokens: beyond FZ_MAX_PATTERN, on this rank only
+                    try:
+                        shard.topk_sharded(comm.handle, bad, 35, 10)
+                        outcome[rank] = "returned"
+                    except _lib.FuzzyHipError as e:
+                        outcome[rank] = str(e)
+                    outcome[(rank, "next")] = shard.topk_sharded(comm.handle, queries, 35, 10)
+                    comm.close()
+            except Exception as e:      # noqa: BLE001
+                errors.append((rank, repr(e)))
+
+        ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        assert not any(t.is_alive() for t in ts), "a rank is still waiting in the collective"
+        assert not errors, errors
+        assert "another rank failed" in outcome[0], outcome[0]
+        assert outcome[1] != "returned" and "another rank" not in outcome[1], outcome[1]
+        for r in range(2):
+            assert same(outcome[(r, "next")], exp[cases[0]]), r
         print("comm case ok:", mode)
         return
     names, queries = corpus_and_queries()

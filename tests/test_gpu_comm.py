@@ -28,5 +28,12 @@ def test_sharded_exchange_ranks_as_threads():
     _run("threads", {"FUZZYHIP_RCCL_LIB": fake})
 
 
+def test_sharded_local_failure_does_not_hang_the_peers():
+    """a rank whose local top-k step fails still enters the all-gather (zeroed keys, status word 1): it returns its
+    own error, its peer returns FZ_ERR_COMM, and the next call on the same communicator works"""
+    fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+    _run("threads_fail", {"FUZZYHIP_RCCL_LIB": fake})
+
+
 def test_sharded_exchange_real_rccl_one_rank():
     _run("real", {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
