@@ -186,7 +186,7 @@ int fz_query_topk(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, u
  * enqueues it before decoding (FUZZYHIP_SUBMIT_EAGER=1: enqueue at once, behind the running kernels -- no host turn
  * between calls, but the HIP runtime of the PyTorch wheels stalls in such launches).
  *   - at most FZ_MAX_IN_FLIGHT tickets per corpus (a further submit fails with FZ_ERR_LIMIT); every ticket must be
- *     waited for exactly once, in any order; fz_corpus_destroy waits for the GPU but fetches nothing
+ *     waited for exactly once (by one thread), in any order; fz_corpus_destroy waits for the GPU but fetches nothing
  *   - q_cps / q_offs must stay valid and unchanged until the wait: rows whose fused lists overflow are redone from them
  *   - calls of one corpus run on its one stream in the order they were submitted; other entry points may be called
  *     in between (they queue up behind); fz_set_stream must not be called while a ticket is outstanding

@@ -251,7 +251,8 @@ struct fz_corpus {
     // fz_query_topk_submit / fz_query_topk_wait: calls submitted whose result has not been fetched.  `launched` is false
     // while a call only has its tables built (the GPU was busy with the call before it)
     struct Flight {
-        bool busy = false, empty = false, fused = false, launched = false;
+        std::atomic<bool> busy{false};                      // set by submit, cleared by wait (also on its error paths, outside the lock)
+        bool empty = false, fused = false, launched = false;
         int scorer = 0;
         uint64_t seq = 0;
         const uint32_t *q_cps = nullptr; const uint64_t *q_offs = nullptr; uint32_t nq = 0, k = 0, flat = 0;
