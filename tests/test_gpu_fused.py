@@ -221,6 +221,34 @@ def test_submit_wait_two_in_flight(oracle, monkeypatch):
         assert g1 == exp and g2 == exp[2:]
 
 
+def test_submit_wait_from_two_threads():
+    """two threads, one corpus, each with one ticket at a time (so never more than FZ_MAX_IN_FLIGHT): a submit that
+    finds the other thread's call running only builds its tables and is sent out by whichever wait sees the GPU free --
+    possibly the other thread's.  Every result equals the synchronous call's."""
+    cps, offs = synth.make_corpus(150_000, max_chars=64, seed=541)
+    batches = [synth.make_queries(cps, offs, 300 + 50 * i, seed=542 + i, max_chars=64) for i in range(2)]
+    with Corpus(cps, offs) as c:
+        refs = [c.topk(b, 35, 10) for b in batches]
+        errors = []
+
+        def worker(t):
+            try:
+                for _ in range(15):
+                    got = c.topk_wait(c.topk_submit(batches[t], 35, 10))
+                    for a, b in zip(got, refs[t]):
+                        assert (a == b).all()
+            except Exception as e:      # noqa: BLE001 -- reported by the main thread
+                errors.append((t, repr(e)))
+
+        import threading
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        assert not any(t.is_alive() for t in ts) and not errors, errors
+
+
 def test_fused_sharded_exchange(monkeypatch):
     """fz_query_topk_sharded with fused local top-k calls: 2 and 3 ranks as threads over the RCCL stand-in on
     shards of >= 256 tiles (tests/comm_case.py 'threads_fused'), results equal to the single-corpus top-k"""
