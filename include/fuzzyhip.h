@@ -310,6 +310,11 @@ int fz_score_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, ui
  *           Shift-And): `query_norm in target_norm` of substring_match_score (app.py:337-345) and,
  *           with a sentinel in front of both sides, the startswith tests of prefix_match_score
  *           (app.py:320-334)
+ *   kind 4: the number M of matching characters difflib.SequenceMatcher(None, query, candidate) finds
+ *           (Ratcliff/Obershelp: longest common block, earliest in the query, then earliest in the candidate, then the
+ *           same on both sides of it), so that SequenceMatcher.ratio() = 2.0 * M / (|query| + |candidate|)
+ *           (reference app.py:421-424).  Queries of at most 64 code points (FZ_ERR_TOO_LONG beyond); a candidate
+ *           longer than 64 code points gets 0xFFFF ("ask difflib": its junk heuristic starts at 200)
  */
 int fz_distance_all(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                     int kind, uint16_t *out_dist);

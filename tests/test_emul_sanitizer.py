@@ -144,6 +144,30 @@ def test_distances(oracle, runner, tmp_path):
                 assert int(got[qi, i]) == fn(q, s), (kind, q, s)
 
 
+def _difflib_matches(a, b):
+    from difflib import SequenceMatcher
+    return sum(blk.size for blk in SequenceMatcher(None, a, b, autojunk=False).get_matching_blocks())
+
+
+def test_sequence_matcher_matches(runner, tmp_path):
+    """fz_distance_all kind 4 (fz_ro_matches) against the stdlib's difflib.SequenceMatcher itself: small alphabets
+    (many equally long blocks: the earliest-in-a, earliest-in-b rule decides), repeats, one- and two-word patterns,
+    empty strings, candidates beyond 64 symbols (0xFFFF: left to difflib)"""
+    import random
+    rnd = random.Random(131)
+    def word(alpha, lo, hi):
+        return "".join(rnd.choice(alpha) for _ in range(rnd.randint(lo, hi)))
+    cand = [word("ab", 0, 64) for _ in range(90)] + [word("abc", 0, 40) for _ in range(90)] + [word("abcdefghij", 1, 64) for _ in range(120)]
+    cand += ["", "a" * 64, "ab" * 32, "abc" * 21, "x" * 65, "ab" * 50, "coke330ml", "cokezero330mlsleekcan", "b" * 63 + "a"]
+    queries = ["", "a", "ab" * 16, "abcabcabc", "a" * 32, "ba" * 20, word("ab", 33, 64), word("abc", 20, 32), word("abcdefghij", 40, 64),
+               "cokezero330ml", "a" * 64, "ab" * 32]
+    got = _run(runner, tmp_path, 1, 4, cand, queries)
+    for qi, q in enumerate(queries):
+        for i, c in enumerate(cand):
+            exp = 0xFFFF if len(c) > 64 else _difflib_matches(q, c)
+            assert int(got[qi, i]) == exp, (q, c, int(got[qi, i]), exp)
+
+
 def test_topk_under_ties(oracle, runner, tmp_path):
     cps, offs = synth.make_corpus(700, max_chars=32, seed=18, vocab_size=9)
     cand = synth.to_strings(cps, offs)

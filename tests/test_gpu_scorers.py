@@ -220,7 +220,33 @@ def test_advanced_fuzzy_matcher_dropin(oracle):
             got = AdvancedFuzzyMatcher.fuzzy_search(q, candidates, threshold=thr, top_n=top)
             assert got == oracle.advanced_fuzzy_search(q, candidates, thr, top), (thr, top, q)
     assert AdvancedFuzzyMatcher.fuzzy_search("", candidates) == [] and AdvancedFuzzyMatcher.fuzzy_search("coke", []) == []
+    # SequenceMatcher's matches from the GPU for every survivor (fz_distance_all kind 4) and from difflib for every
+    # survivor: the same dicts either way
+    for force in (0, 10 ** 9):
+        AdvancedFuzzyMatcher.SEQUENCE_ON_GPU_FROM = force
+        for q in queries:
+            assert AdvancedFuzzyMatcher.fuzzy_search(q, candidates, threshold=0.3, top_n=40) == oracle.advanced_fuzzy_search(q, candidates, 0.3, 40), (force, q)
+    AdvancedFuzzyMatcher.SEQUENCE_ON_GPU_FROM = 48
     AdvancedFuzzyMatcher.clear_cache()
+
+
+def test_sequence_matcher_matches_kind4():
+    """fz_distance_all kind 4 against difflib.SequenceMatcher (stdlib) on the GPU: 3 000 candidates, small alphabets"""
+    from difflib import SequenceMatcher
+    rnd = random.Random(141)
+    def word(alpha, lo, hi):
+        return "".join(rnd.choice(alpha) for _ in range(rnd.randint(lo, hi)))
+    cand = [word("ab", 0, 64) for _ in range(1000)] + [word("abcd", 0, 50) for _ in range(1000)] + [word("abcdefghijklmnop0123", 1, 64) for _ in range(1000)]
+    cand += ["", "a" * 64, "x" * 65, "ab" * 50]
+    queries = ["", "a", "ab" * 16, "abcabcabc", word("ab", 33, 64), word("abcd", 20, 32), word("abcdefghijklmnop0123", 40, 64), "a" * 64]
+    with Corpus.from_prepared(cand) as c:
+        got = c.distance_all(queries, 4)
+        with pytest.raises(Exception):
+            c.distance_all(["q" * 65], 4)
+    for qi, q in enumerate(queries):
+        for i, s in enumerate(cand):
+            exp = 0xFFFF if len(s) > 64 else sum(b.size for b in SequenceMatcher(None, q, s, autojunk=False).get_matching_blocks())
+            assert int(got[qi, i]) == exp, (q, s, int(got[qi, i]), exp)
 
 
 def test_common_tokens_and_substring_kinds():

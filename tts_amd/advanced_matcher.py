@@ -169,6 +169,8 @@ class AdvancedFuzzyMatcher:
     _max_indexes = 8
     _lock = threading.Lock()
     device = 0
+    SEQUENCE_ON_GPU_FROM = 48        # survivors from which SequenceMatcher's matches are computed by the library (one pass
+                                     # over the list costs about as much as this many difflib runs)
 
     normalize_text = staticmethod(normalize_text)
 
@@ -321,8 +323,38 @@ class AdvancedFuzzyMatcher:
             if sure.size >= top_n:
                 cut = np.partition(sure, sure.size - top_n)[sure.size - top_n]
                 could_pass &= np.maximum(others, seq_ub) >= cut
-        for i in np.nonzero(could_pass)[0].tolist():
-            sequence_score = SequenceMatcher(None, qn, ix.norm[i]).ratio()
+        survivors = np.nonzero(could_pass)[0].tolist()
+        # many survivors (a short, popular query): the matching characters M of SequenceMatcher come from the GPU
+        # (fz_distance_all kind 4, Ratcliff/Obershelp with difflib's tie rules; ratio() = 2.0 * M / (|a| + |b|), difflib's own
+        # expression).  The candidate side carries the sentinel, which the query lacks, so it matches nothing.  0xFFFF: a
+        # candidate beyond the kernel's 64 symbols -- difflib itself.  A handful of survivors: difflib is quicker than a pass
+        seq_m = None
+        if len(survivors) > cls.SEQUENCE_ON_GPU_FROM and 0 < la <= 64:
+            seq_m = ix.c_norm.distance_all([qn], 4)[0]
+        seq_of = None
+        if seq_m is not None:
+            # ... and with thousands of survivors the final scores are taken for all of them at once (the same fp64
+            # operations, element by element), so that the per-candidate Python below only runs for those that can be returned
+            sv = np.asarray(survivors, dtype=np.int64)
+            mm = seq_m[sv].astype(np.int64)
+            seq = np.zeros(sv.size, dtype=np.float64)
+            ok = mm != 0xFFFF
+            seq[ok] = 2.0 * mm[ok] / (la + lb[sv][ok])
+            for t in np.nonzero(~ok)[0].tolist():
+                seq[t] = SequenceMatcher(None, qn, ix.norm[int(sv[t])]).ratio()
+            final = np.maximum.reduce([prefix[sv] * cfg['prefix_weight'], substring[sv] * cfg['substring_weight'],
+                                       seq * cfg['sequence_weight'], j2[sv] * cfg['jaccard_weight'], j3[sv] * 0.75,
+                                       lev_score[sv] * cfg['levenshtein_weight']])
+            pick = np.nonzero(final >= threshold)[0]
+            if top_n is not None and top_n > 0 and pick.size > top_n:     # out[:top_n]: score descending, candidate order among equals
+                pick = np.sort(pick[np.argsort(-final[pick], kind='stable')[:top_n]])
+            survivors = sv[pick].tolist()
+            seq_of = dict(zip(survivors, seq[pick].tolist()))
+        for i in survivors:
+            if seq_of is not None:
+                sequence_score = seq_of[i]
+            else:
+                sequence_score = SequenceMatcher(None, qn, ix.norm[i]).ratio()
             final_score = max(prefix[i] * cfg['prefix_weight'], substring[i] * cfg['substring_weight'],
                               sequence_score * cfg['sequence_weight'], j2[i] * cfg['jaccard_weight'],
                               j3[i] * 0.75, lev_score[i] * cfg['levenshtein_weight'])

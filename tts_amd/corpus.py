@@ -178,7 +178,8 @@ class Corpus:
 
     def distance_all(self, queries, kind: int = 0) -> np.ndarray:
         """Raw distances against every candidate as given (no canonicalisation), original order:
-        uint16 [nq, n].  kind 0 = InDel, 1 = Levenshtein (Myers bit-vector kernel)."""
+        uint16 [nq, n].  kind 0 = InDel, 1 = Levenshtein (Myers bit-vector kernel), 2 = common tokens,
+        3 = substring, 4 = matching characters of difflib.SequenceMatcher (0xFFFF: candidate beyond 64 symbols)."""
         q_cps, q_offs, nq = self._pack_queries(queries)
         out = np.zeros((max(nq, 1), max(self.n, 1)), dtype=np.uint16)
         _lib.check(self._lib.fz_distance_all(self._handle(), _u32(q_cps), _u64(q_offs), nq, int(kind),

@@ -14,6 +14,7 @@
 #define FZ_MODE_PARTIAL 4
 #define FZ_MODE_NHITS 5
 #define FZ_MODE_FIND 6
+#define FZ_MODE_RO 7      // matching characters of difflib.SequenceMatcher (Ratcliff/Obershelp), u16; pattern and candidate <= 64 symbols
 #define FZ_IDX_BITS 40
 #define FZ_EMIT_CAP 2048u          // keys a row can append in the fused top-k path (about 10x what a 1-in-16 sample leaves at k = 64)
 #define FZ_FUSED_MAX_K 64u         // larger k goes through the score matrix
@@ -78,6 +79,7 @@ struct FzScoreParams {
     uint32_t pmax;            // capacity of the per-query token arrays in LDS
     uint32_t ntkw;            // text keep-mask words per lane (ceil(max ndw / 8))
     uint32_t nwaves;          // waves per block
+    uint32_t ro;              // 1: the launch is fz_ro_matches (its own LDS layout: fz_score_lds_bytes)
     const uint32_t *tile_list;// optional: indices of the tiles to cover (null = tile_base .. tile_base+ntiles-1)
     uint32_t tile_base;
     const FzQuery *queries;   // queries of this launch (blockIdx.y indexes it)

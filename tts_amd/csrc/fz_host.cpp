@@ -1562,6 +1562,7 @@ static int launch_rows(fz_corpus *c, int view_kind, int kmode, FzTies ties, cons
         const uint32_t tkd = v.wide ? 16u : 8u;             // symbol dwords per text keep-mask word
         p.ntkw = std::max<uint32_t>(1, (v.max_ndw + tkd - 1) / tkd);
         p.nwaves = 4;
+        p.ro = kmode == FZ_MODE_RO ? 1u : 0u;
         while (p.nwaves > 1 && fz_score_lds_bytes(W, p) > 64 * 1024) p.nwaves >>= 1;
         if (fz_score_lds_bytes(W, p) > 160 * 1024)
             return fail(FZ_ERR_TOO_LONG, "pattern width %d words x candidate length %u does not fit in LDS", W, v.max_len);
@@ -2263,10 +2264,13 @@ static int fz_score_all_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t
 static int fz_distance_all_impl(fz_corpus *c, const uint32_t *q_cps, const uint64_t *q_offs, uint32_t nq,
                                int kind, uint16_t *out_dist)
 {
-    if (kind < 0 || kind > 3) return fail(FZ_ERR_INVALID, "kind must be 0 (InDel), 1 (Levenshtein), 2 (common tokens) or 3 (substring)");
+    if (kind < 0 || kind > 4) return fail(FZ_ERR_INVALID, "kind must be 0 (InDel), 1 (Levenshtein), 2 (common tokens), 3 (substring) or 4 (SequenceMatcher matches)");
     if (nq && c && c->n && !out_dist) return fail(FZ_ERR_INVALID, "null output buffer");
+    if (kind == 4 && nq && q_offs)
+        for (uint32_t i = 0; i < nq; ++i)
+            if (q_offs[i + 1] - q_offs[i] > 64u) return fail(FZ_ERR_TOO_LONG, "kind 4 (SequenceMatcher matches) takes queries of at most 64 code points");
     RunOut o; o.dists = out_dist;
-    static const int kModes[4] = {FZ_MODE_INDEL, FZ_MODE_LEV, FZ_MODE_NHITS, FZ_MODE_FIND};
+    static const int kModes[5] = {FZ_MODE_INDEL, FZ_MODE_LEV, FZ_MODE_NHITS, FZ_MODE_FIND, FZ_MODE_RO};
     return run_queries(c, q_cps, q_offs, nq, kind == 2 ? VIEW_SET : VIEW_RAW, kModes[kind],
                        FzTies{0, 0}, 0, 0, RUN_DIST_ALL, o);
 }

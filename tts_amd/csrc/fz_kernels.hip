@@ -353,6 +353,110 @@ __global__ __launch_bounds__(256) void fz_score_general(FzScoreParams p)
 
 
 // ---------------------------------------------------------------------------------------------
+// Ratcliff/Obershelp matching characters: what difflib.SequenceMatcher(None, query, candidate) counts
+// ---------------------------------------------------------------------------------------------
+// reference app.py:329-337 (`SequenceMatcher(None, a, b).ratio()` = 2 * M / (|a| + |b|)); the kernel returns M.
+// find_longest_match(alo, ahi, blo, bhi): the longest block a[i:i+k] == b[j:j+k] inside the rectangle; of the
+// longest ones the one that starts earliest in a, of those the one that starts earliest in b; then the same to the
+// left and to the right of it.  (difflib's "junk" heuristic starts at |b| >= 200; this kernel takes |a|, |b| <= 64
+// and answers 0xFFFF otherwise: the host keeps difflib for those.)
+// One candidate per lane, the query's Peq table in LDS as in fz_score_general.  Per lane, in LDS:
+//   R[j]  match mask of b[j] over the positions of a (one word: |a| <= 32, two: <= 64)
+//   S[j]  pass k: the positions i such that a block of length k ENDS at (i, j) inside the rectangle;
+//         S_1[j] = R[j] & amask, S_{k+1}[j] = (S_k[j-1] << 1) & R[j] & amask, in place with j descending.
+//         The last non-empty pass gives the longest length; its smallest set bit, then smallest j, is the block.
+//   a stack of rectangles (their a-ranges are disjoint and non-empty: at most 64 entries)
+template <int W> struct FzRoWord { typedef uint32_t T; };
+template <> struct FzRoWord<2> { typedef uint64_t T; };
+__device__ __forceinline__ uint32_t fz_ro_ctz(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+__device__ __forceinline__ uint32_t fz_ro_ctz(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+
+template <int W, bool WIDE>
+__global__ __launch_bounds__(256) void fz_ro_matches(FzScoreParams p)
+{
+    using SY = FzSym<WIDE>;
+    typedef typename FzRoWord<W>::T T;
+    constexpr uint32_t RS = fz_peq_stride(W);
+    constexpr uint32_t NMAX = 64u;                                // longest pattern / candidate taken
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t *s_peq = lds;                                        // [peq_rows][RS]
+    uint32_t *m32 = s_peq + p.peq_rows * RS;                      // WIDE: symbol -> row map
+    const uint16_t *s_map = reinterpret_cast<const uint16_t *>(m32);
+    uint32_t head = p.peq_rows * RS + (WIDE ? (p.alphabet + 1u) / 2u : 0u);
+    head = (head + 1u) & ~1u;                                     // the per-wave arrays hold 64-bit words
+    const FzQuery q = p.queries[blockIdx.y];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < q.peq_rows * (uint32_t)W; i += blockDim.x) s_peq[(i / (uint32_t)W) * RS + i % (uint32_t)W] = p.qblob[q.peq_off + i];
+    if (WIDE)
+        for (uint32_t i = tid; i < (p.alphabet + 1u) / 2u; i += blockDim.x) m32[i] = p.qblob[q.map_off + i];
+    __syncthreads();
+    constexpr uint32_t WAVE_WORDS = 64u * (2u * NMAX * (uint32_t)(sizeof(T) / 4u) + NMAX);
+    T *s_R = reinterpret_cast<T *>(lds + head + wave * WAVE_WORDS) + lane;          // [j][lane]
+    T *s_S = s_R + NMAX * 64u;
+    uint32_t *s_st = reinterpret_cast<uint32_t *>(s_S + NMAX * 64u - lane) + lane;  // [depth][lane]
+    const uint32_t m = q.m;
+
+    uint32_t t_end = (blockIdx.x + 1u) * p.tiles_per_block;
+    if (t_end > p.ntiles) t_end = p.ntiles;
+    for (uint32_t tix = blockIdx.x * p.tiles_per_block + wave; tix < t_end; tix += p.nwaves) {
+        const uint32_t tile = p.tile_list ? p.tile_list[tix] : p.tile_base + tix;
+        const FzTile td = p.tiles[tile];
+        const uint32_t clen = td.ntok ? p.tokend[td.toff + lane] : 0u;     // raw view: one slot = the length
+        const uint32_t *symp = p.sym + td.coff + lane;
+        const bool taken = m <= 32u * (uint32_t)W && m <= NMAX && clen <= NMAX;
+        const uint32_t ndw = (uint32_t)td.ndw < NMAX / (uint32_t)SY::SPD ? (uint32_t)td.ndw : NMAX / (uint32_t)SY::SPD;
+        for (uint32_t d = 0; d < ndw; ++d) {
+            const uint32_t cw = symp[d * 64u];
+#pragma unroll
+            for (int k = 0; k < SY::SPD; ++k) {
+                const uint32_t j = d * (uint32_t)SY::SPD + (uint32_t)k;
+                const uint32_t s = (cw >> (SY::BITS * k)) & SY::MASK;
+                const uint32_t *row = s_peq + (WIDE ? (uint32_t)s_map[s] : s) * RS;
+                T r = (T)row[0];
+                if (W == 2) r |= (T)((uint64_t)row[W - 1] << 32);
+                s_R[j * 64u] = j < clen ? r : (T)0;                       // padding symbols match nothing
+            }
+        }
+        uint32_t M = 0u, sp = 0u;
+        if (taken && m != 0u && clen != 0u) { s_st[0] = m << 8 | clen << 24; sp = 1u; }     // {alo, ahi, blo, bhi} bytes
+        while (sp != 0u) {
+            --sp;
+            const uint32_t rect = s_st[sp * 64u];
+            const uint32_t alo = rect & 0xFFu, ahi = (rect >> 8) & 0xFFu, blo = (rect >> 16) & 0xFFu, bhi = rect >> 24;
+            const T ones = ~(T)0;
+            const T amask = (ahi >= 8u * sizeof(T) ? ones : (((T)1 << ahi) - (T)1)) & ~(((T)1 << alo) - (T)1);
+            T any = 0;
+            uint32_t bi = 0xFFFFFFFFu, bj = 0u;                            // end of the best block so far
+            for (uint32_t j = bhi; j-- > blo;) {
+                const T sj = s_R[j * 64u] & amask;
+                s_S[j * 64u] = sj;
+                any |= sj;
+                if (sj != (T)0) { const uint32_t i = fz_ro_ctz(sj); if (i <= bi) { bi = i; bj = j; } }
+            }
+            if (any == (T)0) continue;
+            uint32_t k = 1u;
+            for (;;) {
+                T any2 = 0;
+                uint32_t ci = 0xFFFFFFFFu, cj = 0u;
+                for (uint32_t j = bhi; j-- > blo + k;) {
+                    const T t = (T)(s_S[(j - 1u) * 64u] << 1) & s_R[j * 64u] & amask;
+                    s_S[j * 64u] = t;
+                    any2 |= t;
+                    if (t != (T)0) { const uint32_t i = fz_ro_ctz(t); if (i <= ci) { ci = i; cj = j; } }
+                }
+                if (any2 == (T)0) break;
+                ++k; bi = ci; bj = cj;
+            }
+            M += k;
+            const uint32_t ia = bi + 1u - k, jb = bj + 1u - k;             // where the block starts
+            if (alo < ia && blo < jb) { s_st[sp * 64u] = alo | ia << 8 | blo << 16 | jb << 24; ++sp; }
+            if (ia + k < ahi && jb + k < bhi) { s_st[sp * 64u] = (ia + k) | ahi << 8 | (jb + k) << 16 | bhi << 24; ++sp; }
+        }
+        reinterpret_cast<uint16_t *>(p.scores)[(uint64_t)q.out_row * p.row_stride + (uint64_t)tile * 64u + lane] = taken ? (uint16_t)M : (uint16_t)0xFFFFu;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // partial_ratio kernel (thefuzz.fuzz.partial_ratio, reference app.py:1023)
 // ---------------------------------------------------------------------------------------------
 // rapidfuzz partial_ratio: with `s` the shorter and `l` the longer string, the best ratio(s, w) over
@@ -2120,6 +2224,11 @@ int fz_pick_width(uint32_t m)
 
 size_t fz_score_lds_bytes(int W, const FzScoreParams &p)
 {
+    if (p.ro) {                                                   // fz_ro_matches: Peq, map, then per wave R | S | stack
+        size_t head = (size_t)p.peq_rows * fz_peq_stride(W) + (p.wide ? ((size_t)p.alphabet + 1ull) / 2ull : 0ull);
+        head = (head + 1ull) & ~1ull;
+        return 4ull * (head + (size_t)p.nwaves * 64ull * (2ull * 64ull * (W == 1 ? 1ull : 2ull) + 64ull));
+    }
     return 4ull * ((size_t)p.peq_rows * fz_peq_stride(W) + 3ull * p.pmax + (size_t)p.nwaves * 64ull * ((size_t)W + p.ntkw) +
                    (p.wide ? ((size_t)p.alphabet + 1ull) / 2ull : 0ull));
 }
@@ -2160,10 +2269,31 @@ static hipError_t launch_partial(const FzScoreParams &p, dim3 grid, size_t lds, 
     return p.wide ? launch_partial2<W, true>(p, grid, lds, st) : launch_partial2<W, false>(p, grid, lds, st);
 }
 
+template <int W, bool WIDE>
+static hipError_t launch_ro2(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fz_ro_matches<W, WIDE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((fz_ro_matches<W, WIDE>), grid, dim3(p.nwaves * 64u), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int W>
+static hipError_t launch_ro(const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
+{
+    if constexpr (W <= 2) return p.wide ? launch_ro2<W, true>(p, grid, lds, st) : launch_ro2<W, false>(p, grid, lds, st);
+    else return hipErrorInvalidValue;                             // patterns beyond 64 symbols: refused by the host
+}
+
 template <int W>
 static hipError_t launch_general(int mode, const FzScoreParams &p, dim3 grid, size_t lds, hipStream_t st)
 {
+    if ((mode == FZ_MODE_RO) != (p.ro != 0u)) return hipErrorInvalidValue;
     switch (mode) {
+    case FZ_MODE_RO: return launch_ro<W>(p, grid, lds, st);
     case FZ_MODE_PARTIAL: return launch_partial<W>(p, grid, lds, st);
     case FZ_MODE_TOKEN_SET: return launch_general2<W, FZ_MODE_TOKEN_SET>(p, grid, lds, st);
     case FZ_MODE_RATIO: return launch_general2<W, FZ_MODE_RATIO>(p, grid, lds, st);
